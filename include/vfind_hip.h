@@ -1,0 +1,151 @@
+/*
+ * vfind_hip.h -- C ABI of the MI355X-native variant-extraction engine (libvfind_hip.so).
+ *
+ * This is the drop-in boundary for vFind's per-read hot path.  A host written in any language
+ * (the reference's Rust/PyO3 host, the C++/Python host shipped here) binds exactly these entry
+ * points; nothing in the signatures is a torch, HIP or C++ type.  Each entry point names the
+ * reference interface it replaces (reference = nsbuitrago/vfind 0.3.1, src/lib.rs).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a VF_E* code; vf_last_error() returns the message
+ *     of the last failure on the calling thread (no exceptions or panics cross the ABI);
+ *   - a vf_ctx is owned by one submitting thread at a time;
+ *   - "host" pointers are ordinary CPU memory, "device" pointers are HBM addresses on the
+ *     context's GPU (hipMalloc / torch allocations are both fine);
+ *   - coordinates are in bases, 0-based, as find_adapter_match returns them; -1 means None.
+ */
+#ifndef VFIND_HIP_H
+#define VFIND_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VF_ABI_VERSION 1
+
+enum {
+    VF_OK = 0,
+    VF_EINVAL = 1,    /* bad argument; Python maps it to ValueError                     */
+    VF_EIO = 2,       /* cannot open / read the input; Python maps it to OSError       */
+    VF_EFORMAT = 3,   /* not gzip / malformed FASTQ; reference panics (lib.rs:308)     */
+    VF_EDEVICE = 4,   /* HIP runtime failure                                           */
+    VF_ECAPACITY = 5, /* device count table or key arena full                          */
+    VF_ENOMEM = 6
+};
+
+/* Keyword arguments of find_variants (src/lib.rs:169-182, 219-232) plus device placement.
+ * The library derives skip_*_alignment and the integer score thresholds exactly as
+ * align_threshold_preflight (lib.rs:100-110) and lib.rs:260-261 do. */
+typedef struct vf_params {
+    const uint8_t *prefix;           /* adapters.0 bytes (lib.rs:240) */
+    uint32_t prefix_len;
+    const uint8_t *suffix;           /* adapters.1 bytes (lib.rs:250) */
+    uint32_t suffix_len;
+    int32_t match_score;             /* default 3  */
+    int32_t mismatch_score;          /* default -2 */
+    int32_t gap_open_penalty;        /* default 5  */
+    int32_t gap_extend_penalty;      /* default 2  */
+    double accept_prefix_alignment;  /* default 0.75; 1.0 = exact only */
+    double accept_suffix_alignment;  /* default 0.75 */
+    uint32_t n_threads;              /* host decode workers (lib.rs:178), default 3 */
+    uint32_t queue_len;              /* batches in flight per GPU (lib.rs:179), default 2 */
+    int32_t skip_translation;        /* lib.rs:180 */
+    int32_t device;                  /* HIP device ordinal */
+    uint64_t table_slots;            /* count-table slots, power of two; 0 = default (2^24) */
+    uint64_t arena_bytes;            /* key arena bytes; 0 = default (1 GiB) */
+    uint32_t batch_reads;            /* reads per device batch; 0 = default (2^20) */
+    uint32_t reserved;
+} vf_params;
+
+typedef struct vf_ctx vf_ctx;
+typedef struct vf_result vf_result;
+
+/* Counters and device timings of a context since creation / vf_stats_reset. */
+typedef struct vf_stats {
+    uint64_t reads;            /* reads submitted                                        */
+    uint64_t reads_generic;    /* reads routed through the byte-wise (non-ACGT) kernel   */
+    uint64_t dp_prefix;        /* semi-global alignments run for the prefix adapter      */
+    uint64_t dp_suffix;        /* semi-global alignments run for the suffix adapter      */
+    uint64_t accepted;         /* reads with start < end                                 */
+    uint64_t counted;          /* reads that incremented a key (after the len%3 drop)    */
+    uint64_t table_entries;    /* distinct keys on the device                            */
+    uint64_t arena_dwords;     /* key arena use                                          */
+    /* device time per kernel, milliseconds, summed over launches (HIP events on the
+       context's stream; filled only while profiling is on) */
+    double ms_scan, ms_dp_prefix, ms_dp_suffix, ms_finish, ms_generic;
+    uint64_t launches_scan, launches_dp_prefix, launches_dp_suffix, launches_finish, launches_generic;
+} vf_stats;
+
+const char *vf_last_error(void);
+int vf_abi_version(void);
+
+/* Replaces the set-up half of find_variants (lib.rs:233-261): validates both thresholds
+ * (prefix first) with the reference's message "Accept alignment threshold must be between 0
+ * and 1.", builds the adapter parameter block and allocates the device state. */
+int vf_ctx_create(const vf_params *params, vf_ctx **out);
+void vf_ctx_destroy(vf_ctx *ctx);
+
+/* Replaces File::open -> MultiGzDecoder -> Reader -> parallel_fastq(work, func)
+ * (lib.rs:233-234, 271-308) for one gzip FASTQ file: decode on host threads, pack, stream to
+ * HBM overlapped with the previous batch, run the device path.  May be called repeatedly. */
+int vf_run_fastq(vf_ctx *ctx, const char *path);
+
+/* Replaces the `work` + `func` closures (lib.rs:275-306) for one record set held in host
+ * memory: n_reads sequences, read r = bytes[offsets[r] .. offsets[r+1]).  Asynchronous with
+ * respect to the device; buffers may be reused on return. */
+int vf_submit_ascii(vf_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, uint64_t n_reads);
+
+/* Same for a batch already 2-bit packed by the host (A=0 C=1 G=2 T=3, base k of a read at
+ * bits [2k,2k+1] of its row, little-endian dwords, row_dwords in {10,20,40}); ACGT-only reads. */
+int vf_submit_packed(vf_ctx *ctx, const uint32_t *rows, uint32_t row_dwords, const uint16_t *lens,
+                     uint64_t n_reads);
+
+/* Same for a packed batch already resident in HBM (the kernel-only benchmark path).  d_spans
+ * may be NULL; otherwise it receives n_reads {int16 start, int16 end} pairs (-1 = None). */
+int vf_process_device_packed(vf_ctx *ctx, const void *d_rows, uint32_t row_dwords, const void *d_lens,
+                             uint64_t n_reads, void *d_spans);
+
+/* Test hook at the find_adapter_match boundary (lib.rs:141-166, called at :278-286): per-read
+ * cut coordinates computed by the device path; nothing is counted. */
+int vf_spans_ascii(vf_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, uint64_t n_reads,
+                   int32_t *starts, int32_t *ends);
+
+/* Waits for all submitted work (the end of parallel_fastq, lib.rs:308). */
+int vf_sync(vf_ctx *ctx);
+
+/* Replaces the DataFrame build (lib.rs:312-319): the (sequence, count) table, rows sorted by
+ * count descending then sequence ascending (the reference's order is unspecified). */
+int vf_finish(vf_ctx *ctx, vf_result **out);
+uint64_t vf_result_rows(const vf_result *r);
+const uint8_t *vf_result_key_bytes(const vf_result *r);   /* concatenated UTF-8 keys  */
+const uint64_t *vf_result_key_offsets(const vf_result *r); /* rows+1 offsets           */
+const uint64_t *vf_result_counts(const vf_result *r);      /* rows counts (UInt64)     */
+void vf_result_free(vf_result *r);
+
+/* Empties the device count table (a new find_variants call on a reused context). */
+int vf_table_clear(vf_ctx *ctx);
+
+/* Multi-GPU exchange of the (key,count) table (the reduce of lib.rs:292-306 across GPUs).
+ * vf_table_export_size gives the byte size of this GPU's compacted table; vf_table_export
+ * writes it to device memory the caller owns (e.g. an RCCL send buffer); vf_table_merge adds a
+ * peer's exported table (device memory, e.g. an RCCL receive buffer) into this GPU's table. */
+int vf_table_export_size(vf_ctx *ctx, uint64_t *nbytes);
+int vf_table_export(vf_ctx *ctx, void *d_dst, uint64_t capacity, uint64_t *written);
+int vf_table_merge(vf_ctx *ctx, const void *d_blob, uint64_t nbytes);
+
+int vf_stats_get(vf_ctx *ctx, vf_stats *out);
+int vf_stats_reset(vf_ctx *ctx);
+int vf_set_profiling(vf_ctx *ctx, int on);
+
+/* Host-side helpers shared by hosts that pack themselves. */
+/* 2-bit packs one read; returns 0, or 1 when it holds a byte outside {A,C,G,T}. */
+int vf_pack_read(const uint8_t *seq, uint32_t n, uint32_t *row, uint32_t row_dwords);
+uint32_t vf_row_dwords_for(uint32_t max_read_len); /* 10, 20, 40, or 0 when > 640 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFIND_HIP_H */

@@ -1,0 +1,82 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/vfind_hip.h declares, validates thresholds like the reference (lib.rs:100-110) and fails
+loudly without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT
+
+
+def _lib():
+    from vfind_amd import _lib
+    if not os.path.exists(_lib.SO_PATH):
+        _lib.build()
+    return _lib
+
+
+def test_header_symbols_all_exported():
+    L = _lib()
+    hdr = open(os.path.join(ROOT, "include", "vfind_hip.h")).read()
+    declared = set(re.findall(r"\b(vf_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"vf_params", "vf_ctx", "vf_result", "vf_stats"}
+    assert len(declared) >= 25
+    so = C.CDLL(L.SO_PATH)
+    for name in sorted(declared):
+        assert hasattr(so, name), f"{name} declared in include/vfind_hip.h but not exported"
+    assert {s[0] for s in L.SYMBOLS} == declared
+    assert L.lib().vf_abi_version() == 1
+
+
+def test_pack_read_layout():
+    L = _lib().lib()
+    seq = b"ACGTTGCA" * 5          # 40 bases
+    row = np.zeros(10, np.uint32)
+    assert L.vf_pack_read(seq, len(seq), row.ctypes.data, 10) == 0
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    for k, ch in enumerate(seq):
+        assert (int(row[k // 16]) >> (2 * (k % 16))) & 3 == code[ch]
+    assert row[3:].sum() == 0
+    assert L.vf_pack_read(b"ACGN", 4, row.ctypes.data, 10) == 1
+    assert L.vf_pack_read(b"acgt", 4, row.ctypes.data, 10) == 1
+    assert [L.vf_row_dwords_for(n) for n in (0, 150, 160, 161, 320, 321, 640, 641)] == [10, 10, 10, 20, 20, 40, 40, 0]
+
+
+@pytest.mark.parametrize("bad", [0.0, -0.5, 1.5, float("nan")])
+def test_threshold_validation_matches_reference(bad):
+    from vfind_amd import Engine
+    with pytest.raises(ValueError, match="Accept alignment threshold must be between 0 and 1."):
+        Engine(("ACGT", "TGCA"), accept_prefix_alignment=bad)
+    with pytest.raises(ValueError, match="Accept alignment threshold must be between 0 and 1."):
+        Engine(("ACGT", "TGCA"), accept_suffix_alignment=bad)
+
+
+def test_missing_file_and_bad_args():
+    import vfind_amd
+    with pytest.raises(FileNotFoundError):
+        vfind_amd.find_variants("/nonexistent/x.fq.gz", ("ACGT", "TGCA"))
+    with pytest.raises(TypeError):
+        vfind_amd.Engine(("ACGT",))
+    with pytest.raises(OverflowError):
+        vfind_amd.Engine(("ACGT", "TGCA"), n_threads=-1)
+
+
+def test_no_silent_cpu_fallback():
+    """without a GPU the product must refuse to run rather than compute on the host"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from vfind_amd import Engine, VfindError
+    with pytest.raises((VfindError, RuntimeError)):
+        Engine(("ACGT", "TGCA"))
+
+
+def test_product_does_not_reference_oracle():
+    for d, _, files in os.walk(os.path.join(ROOT, "vfind_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
+                txt = open(os.path.join(d, f), errors="replace").read()
+                assert "oracle" not in txt.replace("no CPU fallback", ""), f"{f} mentions the oracle"

@@ -1,0 +1,248 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle: bit-exact per-read cut
+coordinates and exact (sequence,count) multisets, on the reference's fixture, on seeded synthetic
+reads, and on the edge cases the domain has (short/empty/long reads, N and lowercase bytes,
+adapters the 2-bit path cannot hold, exact-only mode, multi-member gzip)."""
+import csv
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle, pyref
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+TOY = ("GGGCCCAGCCGGCCGGAT", "CCGGAGGCGGAGGTTCAG")
+AD20 = ("GATCGGAAGAGCACACGTCT", "AGATCGGAAGAGCGTCGTGT")
+
+
+def _engine(adapters, **kw):
+    from vfind_amd import Engine
+    return Engine(adapters, table_slots=1 << 16, arena_bytes=1 << 22, **kw)
+
+
+def _check_spans(reads, adapters, **kw):
+    with _engine(adapters, **kw) as e:
+        st, en = e.spans(reads)
+    okw = {k: v for k, v in kw.items() if k not in ("batch_reads",)}
+    ost, oen = oracle.spans(reads, adapters, **okw)
+    bad = np.nonzero((st != ost) | (en != oen))[0]
+    assert bad.size == 0, f"first mismatch read {bad[0]}: gpu=({st[bad[0]]},{en[bad[0]]}) oracle=({ost[bad[0]]},{oen[bad[0]]}) {reads[bad[0]]!r}"
+    return st, en
+
+
+def _check_counts(reads, adapters, **kw):
+    with _engine(adapters, **kw) as e:
+        e.submit(reads)
+        got = e.finish_dict()
+        stats = e.stats()
+    okw = {k: v for k, v in kw.items() if k not in ("batch_reads",)}
+    want = oracle.count(reads, adapters, **okw)
+    assert got == want
+    assert stats["counted"] == sum(want.values())
+    return got
+
+
+def test_reference_fixture_end_to_end(golden_dir):
+    import vfind_amd
+    out = vfind_amd.find_variants(os.path.join(golden_dir, "toy.fq.gz"), TOY, show_progress=False)
+    with open(os.path.join(golden_dir, "ground_truth.csv")) as f:
+        rows = list(csv.reader(f))[1:]
+    cols = {c: (out[c].to_list() if hasattr(out[c], "to_list") else out[c].to_pylist()) for c in ("sequence", "count")}
+    assert list(zip(cols["sequence"], cols["count"])) == [(r[0], int(r[1])) for r in rows] == [("MAGICAL", 4)]
+    names = out.columns if hasattr(out, "columns") else out.column_names
+    assert list(names) == ["sequence", "count"]
+
+
+def test_reference_fixture_modes(golden_dir):
+    import gzip
+    import json
+    import vfind_amd
+    path = os.path.join(golden_dir, "toy.fq.gz")
+    g = json.load(open(os.path.join(golden_dir, "toy_expect.json")))
+    lines = gzip.open(path, "rb").read().split(b"\n")
+    reads = [lines[i + 1] for i in range(0, len(lines) - 1, 4)]
+    st, en = _check_spans(reads, TOY)
+    assert list(st) == [r["start"] for r in g["reads"]] and list(en) == [r["end"] for r in g["reads"]]
+    with vfind_amd.Engine(TOY, accept_prefix_alignment=1.0, accept_suffix_alignment=1.0) as e:
+        e.run_fastq(path)
+        assert e.finish_dict() == {b"MAGICAL": 1}
+    with vfind_amd.Engine(TOY, skip_translation=True) as e:
+        e.run_fastq(path)
+        assert e.finish_dict() == {k.encode(): v for k, v in g["skip_translation"].items()}
+
+
+@pytest.mark.parametrize("seed,L,sub,indel", [(1, 150, 0.005, 0.0005), (2, 150, 0.15, 0.0), (3, 150, 0.05, 0.03), (4, 300, 0.03, 0.01), (5, 600, 0.03, 0.01)])
+def test_spans_parity_random(seed, L, sub, indel):
+    reads = synth.make_reads(seed, 3000, AD20, L=L, sub=sub, indel=indel)
+    st, en = _check_spans(reads, AD20)
+    assert (st >= 0).sum() > 100 and (en >= 0).sum() > 100
+
+
+def test_spans_parity_tie_sensitive_reads_follow_policy_P():
+    # reads whose optimal alignment is not unique: the kernel must agree with the oracle's tie
+    # policy P, and the length it reports must be one of the co-optimal lengths
+    reads = synth.make_reads(11, 1500, AD20, L=100, sub=0.06, indel=0.06, flank_max=7)
+    st, en = _check_spans(reads, AD20)
+    n_tie = 0
+    for i, r in enumerate(reads[:400]):
+        if oracle.find_exact(r, AD20[0]) >= 0 or st[i] < 0:
+            continue
+        score, ends = pyref.cooptimal(AD20[0].encode(), r)
+        lens = {e[2] for e in ends}
+        assert int(st[i]) in lens
+        n_tie += len(lens) > 1
+    assert n_tie > 0, "test input holds no tie-sensitive read"
+
+
+def test_counts_parity_translate_and_skip():
+    reads = synth.make_reads(21, 20000, AD20, L=150, sub=0.01, indel=0.002, n_variants=300)
+    got = _check_counts(reads, AD20)
+    assert len(got) > 50
+    got = _check_counts(reads, AD20, skip_translation=True)
+    assert len(got) > 50
+
+
+def test_counts_parity_variable_length_and_dirty_reads():
+    reads = synth.make_reads(22, 8000, AD20, L=150, sub=0.02, indel=0.005, vary_len=True, dirty=0.2)
+    _check_spans(reads, AD20)
+    _check_counts(reads, AD20)
+    _check_counts(reads, AD20, skip_translation=True)
+
+
+def test_exact_only_six_bp_adapters_cfg1():
+    # BASELINE.json configs[0]: 10k reads, 150 bp, 6 bp adapters, accept=1.0 (exact only)
+    ads = ("GGATCC", "CTCGAG")
+    reads = synth.make_reads(31, 10000, ads, L=150, sub=0.0, indel=0.0, n_variants=1000)
+    kw = dict(accept_prefix_alignment=1.0, accept_suffix_alignment=1.0)
+    _check_spans(reads, ads, **kw)
+    got = _check_counts(reads, ads, **kw)
+    assert len(got) > 100
+
+
+def test_edge_reads():
+    reads = [b"", b"A", b"ACGT", AD20[0].encode(), AD20[1].encode(), (AD20[0] + AD20[1]).encode(),
+             (AD20[0] + "ATG" + AD20[1]).encode(), (AD20[0] + "ATGA" + AD20[1]).encode(),
+             (AD20[1] + "ATGAAA" + AD20[0]).encode(),                       # suffix before prefix
+             (AD20[0] + "ATGAAA" + AD20[1] + "CC" + AD20[1]).encode(),      # leftmost suffix wins
+             b"N" * 150, b"acgt" * 30, (AD20[0][:19] + "N" + "ATGAAA" + AD20[1]).encode(),
+             (AD20[0] + "ATGNNNAAA" + AD20[1]).encode(), (AD20[0] + "atgaaa" + AD20[1]).encode(),
+             (AD20[0] + "AUGAAA" + AD20[1]).encode(), (AD20[0].lower() + "ATGAAA" + AD20[1]).encode(),
+             (AD20[0] + "ATG" * 250 + AD20[1]).encode(),                    # 790 bp: byte-wise path
+             (AD20[0] + "ATG" * 60 + AD20[1]).encode(),                     # 220 bp: W=20
+             (AD20[0] + "\xc3\xa9ATGA" + AD20[1]).encode("latin-1"),         # non-ASCII bytes
+             (AD20[0] + "\xff\xfeAAAA" + AD20[1]).encode("latin-1")]         # invalid UTF-8 region
+    _check_spans(reads, AD20)
+    _check_counts(reads, AD20)
+    _check_counts(reads, AD20, skip_translation=True)
+    with _engine(AD20) as e:
+        e.submit([])
+        assert e.finish_dict() == {}
+
+
+@pytest.mark.parametrize("ads", [("ACGTNACGTACGTACGTACG", "TTGACCAGTNNACGATTGCA"), ("A" * 33 + "CGT", "TGCA" * 10), ("acgtacgtacgtacgt", "TGCATGCATGCATGCA"), ("", "ACGT"), ("ACGTACGTAC", "")])
+def test_adapters_outside_the_fast_path(ads):
+    rd = synth.make_reads(41, 600, ("ACGTTACGTACGTACGTACG", "TTGACCAGTCAACGATTGCA"), L=120)
+    rd += synth.make_reads(42, 400, [a or "ACGT" for a in ads], L=120, sub=0.02)
+    _check_spans(rd, ads)
+    _check_counts(rd, ads)
+
+
+@pytest.mark.parametrize("kw", [dict(match_score=1, mismatch_score=-1, gap_open_penalty=2, gap_extend_penalty=1),
+                                dict(match_score=5, mismatch_score=-4, gap_open_penalty=10, gap_extend_penalty=1, accept_prefix_alignment=0.6, accept_suffix_alignment=0.9),
+                                dict(match_score=2, mismatch_score=-3, gap_open_penalty=0, gap_extend_penalty=0),
+                                dict(match_score=300, mismatch_score=-200, gap_open_penalty=500, gap_extend_penalty=200),
+                                dict(accept_prefix_alignment=0.7, accept_suffix_alignment=1.0)])
+def test_scoring_parameters(kw):
+    reads = synth.make_reads(51, 2500, AD20, L=150, sub=0.06, indel=0.02)
+    _check_spans(reads, AD20, **kw)
+    _check_counts(reads, AD20, **kw)
+
+
+@pytest.mark.parametrize("m", [1, 2, 7, 16, 17, 31, 32])
+def test_adapter_lengths(m):
+    rng = np.random.default_rng(m)
+    ads = (synth.rand_seq(rng, m).decode(), synth.rand_seq(rng, m).decode())
+    reads = synth.make_reads(60 + m, 2000, ads, L=120, sub=0.04, indel=0.01)
+    _check_spans(reads, ads, accept_prefix_alignment=0.8, accept_suffix_alignment=0.8)
+
+
+def test_small_batches_and_slot_reuse():
+    reads = synth.make_reads(71, 5000, AD20, L=150, sub=0.02, indel=0.005, dirty=0.05)
+    _check_counts(reads, AD20, batch_reads=257, queue_len=3)
+    _check_spans(reads, AD20, batch_reads=129)
+
+
+def test_fastq_end_to_end_multimember_gzip(tmp_path):
+    import vfind_amd
+    reads = synth.make_reads(81, 30000, AD20, L=150, sub=0.01, indel=0.002, n_variants=400, dirty=0.01)
+    p = str(tmp_path / "multi.fq.gz")
+    synth.write_fastq_gz(p, reads, members=3)
+    want = oracle.count_fastq(p, AD20)
+    assert want == oracle.count(reads, AD20)
+    with vfind_amd.Engine(AD20, n_threads=4) as e:
+        e.run_fastq(p)
+        assert e.finish_dict() == want
+        assert e.stats()["reads"] == len(reads)
+    p2 = str(tmp_path / "crlf.fq.gz")
+    synth.write_fastq_gz(p2, reads[:500], crlf=True)
+    with vfind_amd.Engine(AD20) as e:
+        e.run_fastq(p2)
+        assert e.finish_dict() == oracle.count(reads[:500], AD20)
+    out = vfind_amd.find_variants(p, AD20, show_progress=False)
+    seqs = out["sequence"].to_list() if hasattr(out["sequence"], "to_list") else out["sequence"].to_pylist()
+    cnts = out["count"].to_list() if hasattr(out["count"], "to_list") else out["count"].to_pylist()
+    assert [(s.encode(), c) for s, c in zip(seqs, cnts)] == list(oracle.sorted_table(want))
+
+
+def test_fastq_errors(tmp_path):
+    import gzip
+    import vfind_amd
+    plain = tmp_path / "plain.fq"
+    plain.write_bytes(b"@r\nACGT\n+\nFFFF\n")
+    with pytest.raises(vfind_amd.VfindError, match="gzip"):
+        vfind_amd.find_variants(str(plain), AD20)
+    for name, body in [("noat.fq.gz", b"r\nACGT\n+\nFFFF\n"), ("qual.fq.gz", b"@r\nACGT\n+\nFFF\n"), ("trunc.fq.gz", b"@r\nACGT\n+\n"), ("plus.fq.gz", b"@r\nACGT\n-\nFFFF\n")]:
+        p = tmp_path / name
+        p.write_bytes(gzip.compress(body))
+        with pytest.raises(vfind_amd.VfindError, match="malformed FASTQ"):
+            vfind_amd.find_variants(str(p), AD20)
+    good = gzip.compress(b"@r\nACGT\n+\nFFFF\n" * 2000)
+    p = tmp_path / "cut.fq.gz"
+    p.write_bytes(good[: len(good) // 2])
+    with pytest.raises(vfind_amd.VfindError):
+        vfind_amd.find_variants(str(p), AD20)
+    p = tmp_path / "nonl.fq.gz"
+    p.write_bytes(gzip.compress(b"@r\n" + (AD20[0] + "ATGAAA" + AD20[1]).encode() + b"\n+\n" + b"F" * 46))
+    out = vfind_amd.Engine(AD20)
+    out.run_fastq(str(p))
+    assert out.finish_dict() == {b"MK": 1}
+    out.close()
+
+
+def test_table_export_merge_and_clear():
+    a = synth.make_reads(91, 6000, AD20, L=150, n_variants=200)
+    b = synth.make_reads(92, 6000, AD20, L=150, n_variants=200)
+    import torch
+    with _engine(AD20) as e1, _engine(AD20) as e2:
+        e1.submit(a)
+        e2.submit(b)
+        n = e2.export_size()
+        buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+        assert e2.export_to(buf.data_ptr(), n + 64) == n
+        e1.merge_from(buf.data_ptr(), n)
+        assert e1.finish_dict() == oracle.count(a + b, AD20)
+        e1.clear()
+        assert e1.finish_dict() == {}
+        e1.submit(b)
+        assert e1.finish_dict() == oracle.count(b, AD20)
+
+
+def test_capacity_error_is_loud():
+    from vfind_amd import Engine, VfindError
+    reads = synth.make_reads(95, 4000, AD20, L=150, n_variants=2000)
+    with Engine(AD20, skip_translation=True, table_slots=64, arena_bytes=1 << 20) as e:
+        e.submit(reads)
+        with pytest.raises(VfindError, match="table full|arena full"):
+            e.finish_dict()

@@ -1,0 +1,248 @@
+"""vfind_amd -- MI355X-native drop-in for vFind's variant-extraction hot path.
+
+Host-side mirror of the reference's only public interface, the PyO3 function `find_variants`
+(reference: src/lib.rs:168-232), over the C ABI of include/vfind_hip.h.  The per-read work --
+adapter match, semi-global alignment fallback, extraction, translation, counting -- runs in
+hand-written HIP kernels (vfind_amd/csrc/vf_kernels.hip); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import VfindError, VfParams, VfStats, check
+
+__all__ = ["find_variants", "Engine", "VfindError", "build"]
+__version__ = "0.1.0"
+
+build = _lib.build
+
+
+def _as_bytes(x) -> bytes:
+    if isinstance(x, str):
+        return x.encode("utf-8")
+    if isinstance(x, (bytes, bytearray, memoryview)):
+        return bytes(x)
+    raise TypeError("adapter must be str")
+
+
+class Engine:
+    """One vf_ctx: a GPU, its count table and its batch pipeline.
+
+    Keyword meaning, defaults and threshold validation follow find_variants (src/lib.rs:169-182,
+    100-110, 260-261).  Extra keywords place the context on a device and size its table.
+    """
+
+    def __init__(self, adapters: Tuple[str, str], match_score: int = 3, mismatch_score: int = -2,
+                 gap_open_penalty: int = 5, gap_extend_penalty: int = 2,
+                 accept_prefix_alignment: float = 0.75, accept_suffix_alignment: float = 0.75,
+                 n_threads: int = 3, queue_len: int = 2, skip_translation: bool = False, *,
+                 device: int = 0, table_slots: int = 0, arena_bytes: int = 0, batch_reads: int = 0):
+        if not isinstance(adapters, (tuple, list)) or len(adapters) != 2:
+            raise TypeError("adapters must be a tuple (prefix, suffix)")
+        self._L = _lib.lib()
+        self._pre, self._suf = _as_bytes(adapters[0]), _as_bytes(adapters[1])
+        for name, v in (("n_threads", n_threads), ("queue_len", queue_len)):
+            if int(v) < 0:
+                raise OverflowError(f"can't convert negative int to unsigned ({name})")
+        p = VfParams(self._pre, len(self._pre), self._suf, len(self._suf), int(match_score), int(mismatch_score),
+                     int(gap_open_penalty), int(gap_extend_penalty), float(accept_prefix_alignment),
+                     float(accept_suffix_alignment), int(n_threads), int(queue_len), int(bool(skip_translation)),
+                     int(device), int(table_slots), int(arena_bytes), int(batch_reads), 0)
+        self._ctx = C.c_void_p()
+        check(self._L.vf_ctx_create(C.byref(p), C.byref(self._ctx)))
+        self.device = int(device)
+        self.skip_translation = bool(skip_translation)
+
+    # ---- lifetime -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.vf_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- submission -----------------------------------------------------------------------------
+    def run_fastq(self, path: str):
+        """gzip FASTQ file -> count table (replaces lib.rs:233-234 + parallel_fastq, :271-308)"""
+        check(self._L.vf_run_fastq(self._ctx, os.fsencode(path)))
+
+    @staticmethod
+    def _pack_list(reads) -> Tuple[np.ndarray, np.ndarray]:
+        reads = [_as_bytes(r) for r in reads]
+        offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+        if reads:
+            offs[1:] = np.cumsum([len(r) for r in reads], dtype=np.uint64)
+        data = np.frombuffer(b"".join(reads), dtype=np.uint8) if reads else np.zeros(0, np.uint8)
+        return np.ascontiguousarray(data), offs
+
+    def submit(self, reads_or_arrays):
+        """a record set held in host memory: list of sequences, or (uint8 bytes, uint64 offsets)"""
+        data, offs = reads_or_arrays if isinstance(reads_or_arrays, tuple) else self._pack_list(reads_or_arrays)
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        check(self._L.vf_submit_ascii(self._ctx, data.ctypes.data, offs.ctypes.data, len(offs) - 1))
+
+    def submit_packed(self, rows: np.ndarray, lens: np.ndarray):
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        lens = np.ascontiguousarray(lens, dtype=np.uint16)
+        check(self._L.vf_submit_packed(self._ctx, rows.ctypes.data, rows.shape[1], lens.ctypes.data, rows.shape[0]))
+
+    def process_device(self, rows_ptr: int, row_dwords: int, lens_ptr: int, n_reads: int, spans_ptr: int = 0):
+        """packed batch resident in HBM (raw device addresses, e.g. tensor.data_ptr())"""
+        check(self._L.vf_process_device_packed(self._ctx, rows_ptr, row_dwords, lens_ptr, n_reads, spans_ptr or None))
+
+    def spans(self, reads_or_arrays) -> Tuple[np.ndarray, np.ndarray]:
+        """per-read find_adapter_match results (lib.rs:278-286) from the device path; -1 = None"""
+        data, offs = reads_or_arrays if isinstance(reads_or_arrays, tuple) else self._pack_list(reads_or_arrays)
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        n = len(offs) - 1
+        st = np.empty(n, np.int32)
+        en = np.empty(n, np.int32)
+        check(self._L.vf_spans_ascii(self._ctx, data.ctypes.data, offs.ctypes.data, n, st.ctypes.data, en.ctypes.data))
+        return st, en
+
+    def sync(self):
+        check(self._L.vf_sync(self._ctx))
+
+    def clear(self):
+        check(self._L.vf_table_clear(self._ctx))
+
+    # ---- results --------------------------------------------------------------------------------
+    def finish_arrays(self):
+        """(key bytes uint8, offsets uint64[rows+1], counts uint64[rows]); count desc, sequence asc"""
+        res = C.c_void_p()
+        check(self._L.vf_finish(self._ctx, C.byref(res)))
+        try:
+            n = self._L.vf_result_rows(res)
+            offs = np.ctypeslib.as_array(C.cast(self._L.vf_result_key_offsets(res), C.POINTER(C.c_uint64)), (n + 1,)).copy()
+            cnts = (np.ctypeslib.as_array(C.cast(self._L.vf_result_counts(res), C.POINTER(C.c_uint64)), (n,)).copy()
+                    if n else np.zeros(0, np.uint64))
+            nb = int(offs[-1])
+            keys = (np.ctypeslib.as_array(C.cast(self._L.vf_result_key_bytes(res), C.POINTER(C.c_uint8)), (nb,)).copy()
+                    if nb else np.zeros(0, np.uint8))
+        finally:
+            self._L.vf_result_free(res)
+        return keys, offs, cnts
+
+    def finish_dict(self) -> dict:
+        keys, offs, cnts = self.finish_arrays()
+        raw = keys.tobytes()
+        return {raw[int(offs[i]):int(offs[i + 1])]: int(cnts[i]) for i in range(len(cnts))}
+
+    def finish(self):
+        """the (sequence, count) frame of lib.rs:312-319: polars if importable, else pyarrow"""
+        return _to_frame(*self.finish_arrays())
+
+    # ---- multi-GPU exchange ----------------------------------------------------------------------
+    def export_size(self) -> int:
+        n = C.c_uint64()
+        check(self._L.vf_table_export_size(self._ctx, C.byref(n)))
+        return int(n.value)
+
+    def export_to(self, dst_ptr: int, capacity: int) -> int:
+        w = C.c_uint64()
+        check(self._L.vf_table_export(self._ctx, dst_ptr, capacity, C.byref(w)))
+        return int(w.value)
+
+    def merge_from(self, src_ptr: int, nbytes: int):
+        check(self._L.vf_table_merge(self._ctx, src_ptr, nbytes))
+
+    def allreduce_table(self, group=None, dst: Optional[int] = 0):
+        """Sum the (key,count) tables of all ranks over RCCL (torch.distributed, backend nccl).
+
+        Every rank exports its compacted table into a torch uint8 CUDA tensor, the tables are
+        all-gathered (padded to the largest), and rank `dst` (or every rank when dst is None)
+        merges its peers' tables on the device.  Returns merge time in seconds on merging ranks.
+        """
+        import time
+
+        import torch
+        import torch.distributed as dist
+
+        world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
+        if world == 1:
+            return 0.0
+        dev = torch.device("cuda", self.device)
+        mine = self.export_size()
+        sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+        sizes[rank] = mine
+        dist.all_reduce(sizes, group=group)
+        cap = int(sizes.max().item())
+        cap = (cap + 255) // 256 * 256
+        send = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        self.export_to(send.data_ptr(), cap)
+        recv = torch.empty(world * cap, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        if dst is None or rank == dst:
+            for r in range(world):
+                if r != rank:
+                    self.merge_from(recv.data_ptr() + r * cap, int(sizes[r].item()))
+        return time.perf_counter() - t0
+
+    # ---- stats ----------------------------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        check(self._L.vf_set_profiling(self._ctx, int(bool(on))))
+
+    def stats(self) -> dict:
+        s = VfStats()
+        check(self._L.vf_stats_get(self._ctx, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in VfStats._fields_}
+
+    def reset_stats(self):
+        check(self._L.vf_stats_reset(self._ctx))
+
+
+def _to_frame(keys: np.ndarray, offs: np.ndarray, cnts: np.ndarray):
+    raw = keys.tobytes()
+    seqs = [raw[int(offs[i]):int(offs[i + 1])].decode("utf-8") for i in range(len(cnts))]
+    try:
+        import polars as pl
+    except ImportError:
+        import pyarrow as pa
+        return pa.table({"sequence": pa.array(seqs, type=pa.string()), "count": pa.array(cnts, type=pa.uint64())})
+    return pl.DataFrame({"sequence": pl.Series(seqs, dtype=pl.String), "count": pl.Series(cnts, dtype=pl.UInt64)})
+
+
+def find_variants(fq_path: str, adapters: Tuple[str, str], match_score: int = 3, mismatch_score: int = -2,
+                  gap_open_penalty: int = 5, gap_extend_penalty: int = 2, accept_prefix_alignment: float = 0.75,
+                  accept_suffix_alignment: float = 0.75, n_threads: int = 3, queue_len: int = 2,
+                  skip_translation: bool = False, show_progress: bool = True, *, device: int = 0,
+                  table_slots: int = 0, arena_bytes: int = 0):
+    """Find variable regions flanked by adapters in a FASTQ dataset.
+
+    Same positional/keyword signature, defaults and errors as the reference's `find_variants`
+    (src/lib.rs:169-182, 219-232): a bad threshold raises ValueError("Accept alignment threshold
+    must be between 0 and 1."), a missing file raises FileNotFoundError.  `show_progress` is
+    accepted and ignored (the reference's spinner is never ticked, lib.rs:265-269, 310).
+
+    Returns a frame with columns `sequence` (String) and `count` (UInt64): polars.DataFrame when
+    polars is importable, else a pyarrow.Table of the same schema.  Row order (unspecified in the
+    reference, lib.rs:312) is count descending, then sequence ascending.
+    """
+    del show_progress
+    with open(fq_path, "rb"):          # File::open(fq_path)? comes first in the reference (lib.rs:233)
+        pass
+    with Engine(adapters, match_score, mismatch_score, gap_open_penalty, gap_extend_penalty,
+                accept_prefix_alignment, accept_suffix_alignment, n_threads, queue_len, skip_translation,
+                device=device, table_slots=table_slots, arena_bytes=arena_bytes) as eng:
+        eng.run_fastq(fq_path)
+        return eng.finish()

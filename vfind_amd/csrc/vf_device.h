@@ -1,0 +1,106 @@
+// vf_device.h -- structures shared by the host runtime (vf_host.cpp) and the gfx950 kernels
+// (vf_kernels.hip).  Internal; the public boundary is include/vfind_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vf {
+
+// ---- packed-read geometry -------------------------------------------------------------------
+// A read is a row of W little-endian dwords, base k at bits [2k,2k+1]; A=0 C=1 G=2 T=3.
+constexpr int kMaxFastAdapter = 32;   // rows of the DP kept in VGPRs; adapter fits one u64
+constexpr int kMaxFastRead = 640;     // W = 40
+constexpr int16_t kNone = -1;         // span coordinate: no match          (Option::None)
+constexpr int16_t kPending = -2;      // span coordinate: waits for the DP kernel
+
+// ---- packed DP cell value (see DESIGN.md "DP cell encoding") ---------------------------------
+//   bits 31..13  score, biased by -mismatch*row      (signed)
+//   bits 12..10  tie preference (diag 6 > F 5/4 > E 1/0), cleared/normalised after every max
+//   bits  9..0   alignment length, biased by 32-row
+constexpr int kScoreShift = 13;
+constexpr int kPrefShift = 10;
+constexpr uint32_t kPrefMask = 7u << kPrefShift;
+constexpr uint32_t kLenMask = (1u << kPrefShift) - 1u;
+constexpr int kLenBias = 32;
+constexpr int kNegScore = -20000;
+
+struct DpParams {
+    uint64_t pat;        // adapter, 2 bits per base
+    uint32_t m;          // adapter length (1..32)
+    uint32_t eq[4];      // eq[c] bit i set <=> adapter base i == c
+    int32_t T;           // accept iff score >= T
+    int32_t mismatch;    // for un-biasing
+    int32_t e_open_k, e_ext_k, f_open_k, f_ext_k;  // packed additive constants
+    uint32_t delta;      // (match - mismatch) << kScoreShift
+    uint32_t pref_clear; // ~kPrefMask (kept opaque so it stays in an SGPR for v_and_or_b32)
+    uint32_t pref6;      // 6 << kPrefShift
+    uint32_t is_prefix;
+};
+
+struct ScanParams {
+    uint64_t pre_pat, suf_pat;
+    uint32_t pre_len, suf_len;
+    uint32_t align_pre, align_suf;   // 1 = semi-global fallback enabled for that adapter
+};
+
+// ---- generic (byte-wise) path ---------------------------------------------------------------
+struct GenericParams {
+    const uint8_t *pre, *suf;      // device copies of the ASCII adapters
+    uint32_t pre_len, suf_len;
+    uint32_t align_pre, align_suf;
+    int64_t T_pre, T_suf;
+    int32_t match, mismatch, open, ext;
+    uint32_t skip_translation;
+    uint32_t count_mode;           // 1 = insert keys, 0 = spans only
+};
+
+// ---- device count table ---------------------------------------------------------------------
+// Open addressing, linear probing.  tags[s]==0 <=> empty.  refs[s]==0 <=> key not yet published.
+// ref = off_dwords<<24 | 1<<23 | kind<<16 | len     (len: bytes for kind 0, bases for kind 1)
+constexpr uint64_t kRefValid = 1ull << 23;
+constexpr uint64_t kRefOverflow = ~0ull;
+enum { kKindBytes = 0, kKindPacked = 1 };
+
+enum Counter : int {        // uint64 counters[] in device memory
+    C_ARENA_TOP = 0,        // dwords
+    C_ENTRIES = 1,
+    C_ERROR = 2,            // bit0 arena full, bit1 table full
+    C_ACCEPTED = 3,
+    C_COUNTED = 4,
+    C_DP_PREFIX = 5,
+    C_DP_SUFFIX = 6,
+    C_EXPORT_N = 7,
+    C_NUM = 8
+};
+
+struct Table {
+    uint32_t *tags;
+    uint64_t *refs;
+    uint64_t *counts;
+    uint32_t *arena;
+    uint64_t *counters;
+    uint32_t slot_mask;
+    uint64_t arena_cap;     // dwords
+};
+
+// ---- launchers (vf_kernels.hip) ---------------------------------------------------------------
+struct BatchLists {        // per in-flight batch
+    uint32_t *listP, *listS;
+    uint32_t *cnt;         // [0]=nP, [1]=nS
+};
+
+hipError_t launch_scan(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n,
+                       const ScanParams &sp, short2 *spans, BatchLists bl);
+hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n_bound,
+                     const uint32_t *list, const uint32_t *count, const DpParams &dp, short2 *spans,
+                     uint32_t *listS, uint32_t *countS, uint64_t *counters);
+hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n,
+                         const short2 *spans, uint32_t skip_translation, Table t);
+hipError_t launch_generic(hipStream_t s, const uint8_t *bytes, const uint64_t *offs, uint64_t n,
+                          const GenericParams &gp, int32_t *starts, int32_t *ends, int32_t *ws,
+                          uint64_t ws_stride, uint32_t ws_rows, Table t);
+hipError_t launch_export(hipStream_t s, Table t, uint64_t *out_refs, uint64_t *out_counts);
+hipError_t launch_merge(hipStream_t s, Table t, const uint64_t *refs, const uint64_t *counts,
+                        const uint32_t *arena, uint64_t n);
+
+}  // namespace vf

@@ -1,0 +1,1013 @@
+// vf_host.cpp -- host runtime behind the C ABI of include/vfind_hip.h.
+//
+// Owns: parameter derivation (lib.rs:100-110, 236-261), gzip FASTQ decode and 2-bit packing on
+// host threads into pinned staging, the per-GPU batch pipeline (hipMemcpyAsync of batch k+1
+// overlapped with the kernels of batch k on per-slot streams), the device count table, and the
+// result build (lib.rs:312-319).  No CPU fallback exists: every per-read decision is made by the
+// kernels in vf_kernels.hip; the host only decodes, packs, launches and formats.
+#include "../../include/vfind_hip.h"
+#include "vf_device.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+using namespace vf;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail(VF_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));           \
+    } while (0)
+
+extern "C" const char *vf_last_error(void) { return g_err.c_str(); }
+extern "C" int vf_abi_version(void) { return VF_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------------
+// packing
+// ------------------------------------------------------------------------------------------------
+static uint8_t g_code[256];
+static std::once_flag g_code_once;
+static void init_code() {
+    memset(g_code, 0xFF, sizeof(g_code));
+    g_code[(int)'A'] = 0; g_code[(int)'C'] = 1; g_code[(int)'G'] = 2; g_code[(int)'T'] = 3;
+}
+
+extern "C" uint32_t vf_row_dwords_for(uint32_t max_len) {
+    if (max_len <= 160) return 10;
+    if (max_len <= 320) return 20;
+    if (max_len <= 640) return 40;
+    return 0;
+}
+
+// 2-bit pack; returns 1 when a byte outside {A,C,G,T} is met (row content then undefined)
+extern "C" int vf_pack_read(const uint8_t *seq, uint32_t n, uint32_t *row, uint32_t row_dwords) {
+    std::call_once(g_code_once, init_code);
+    if (n > row_dwords * 16u) return 1;
+    uint32_t bad = 0;
+    uint32_t full = n / 16;
+    for (uint32_t w = 0; w < full; ++w) {
+        const uint8_t *p = seq + 16 * w;
+        uint32_t v = 0;
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t c = g_code[p[k]];
+            bad |= c;
+            v |= (c & 3u) << (2 * k);
+        }
+        row[w] = v;
+    }
+    uint32_t w = full;
+    if (n % 16) {
+        const uint8_t *p = seq + 16 * w;
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < n % 16; ++k) {
+            const uint32_t c = g_code[p[k]];
+            bad |= c;
+            v |= (c & 3u) << (2 * k);
+        }
+        row[w++] = v;
+    }
+    for (; w < row_dwords; ++w) row[w] = 0;
+    return (bad & 0x80u) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct EventPair { hipEvent_t a, b; int kind; };
+enum { K_SCAN = 0, K_DPP, K_DPS, K_FIN, K_GEN, K_KINDS };
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;   // elements
+    int ensure(size_t n) {
+        if (n <= cap) return VF_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = std::max(n, (size_t)16);
+        if (hipMalloc((void **)&p, want * sizeof(T)) != hipSuccess) return fail(VF_ENOMEM, "hipMalloc failed");
+        cap = want;
+        return VF_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+template <typename T> struct PinBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return VF_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        size_t want = std::max(n, (size_t)16);
+        if (hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault) != hipSuccess) return fail(VF_ENOMEM, "hipHostMalloc failed");
+        cap = want;
+        return VF_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+struct Workspace {               // device scratch of one in-flight batch
+    DevBuf<short2> spans;
+    DevBuf<uint32_t> listP, listS, cnt;
+    int ensure(size_t n) {
+        int rc;
+        if ((rc = spans.ensure(n))) return rc;
+        if ((rc = listP.ensure(n))) return rc;
+        if ((rc = listS.ensure(n))) return rc;
+        return cnt.ensure(4);
+    }
+    void release() { spans.release(); listP.release(); listS.release(); cnt.release(); }
+};
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    bool busy = false;           // owned by a submitting thread
+    bool in_flight = false;      // event recorded, not yet waited
+    // fast path staging
+    PinBuf<uint32_t> h_rows; PinBuf<uint16_t> h_lens;
+    DevBuf<uint32_t> d_rows; DevBuf<uint16_t> d_lens;
+    Workspace ws;
+    // generic path staging
+    PinBuf<uint8_t> h_gbytes; PinBuf<uint64_t> h_goffs;
+    DevBuf<uint8_t> d_gbytes; DevBuf<uint64_t> d_goffs;
+    DevBuf<int32_t> d_gstart, d_gend, d_gws;
+    PinBuf<int32_t> h_gstart, h_gend;
+    PinBuf<short2> h_spans;
+    std::vector<uint32_t> fast_idx, gen_idx;   // original positions (vf_spans_ascii)
+};
+
+struct ReadRef { uint64_t off; uint32_t len; };
+
+}  // namespace
+
+struct vf_ctx {
+    int dev = 0;
+    // derived parameters
+    std::string pre, suf;
+    int32_t match = 3, mismatch = -2, gopen = 5, gext = 2;
+    bool skip_pre = false, skip_suf = false;   // skip alignment (accept == 1.0)
+    int64_t T_pre = 0, T_suf = 0;
+    bool skip_translation = false;
+    bool fast_ok = false;
+    uint32_t n_threads = 3, queue_len = 2, batch_reads = 1u << 18;
+    ScanParams sp{};
+    DpParams dpP{}, dpS{};
+    GenericParams gp{};
+    DevBuf<uint8_t> d_adapters;
+    // table
+    Table tab{};
+    uint64_t table_slots = 0, arena_dwords = 0;
+    DevBuf<uint32_t> t_tags; DevBuf<uint64_t> t_refs, t_counts; DevBuf<uint32_t> t_arena; DevBuf<uint64_t> t_counters;
+    // pipeline
+    std::vector<std::unique_ptr<Slot>> slots;
+    std::mutex mu;
+    std::condition_variable cv;
+    hipStream_t main_stream = nullptr;
+    Workspace resident;          // for vf_process_device_packed
+    DevBuf<uint64_t> exp_refs, exp_counts;
+    // stats / profiling
+    std::atomic<uint64_t> n_reads{0}, n_generic{0};
+    bool profiling = false;
+    std::mutex ev_mu;
+    std::vector<EventPair> pending_events;
+    double ms[K_KINDS] = {0, 0, 0, 0, 0};
+    uint64_t launches[K_KINDS] = {0, 0, 0, 0, 0};
+    // async error from worker threads
+    std::mutex err_mu;
+    int async_rc = 0;
+    std::string async_msg;
+};
+
+struct vf_result {
+    std::vector<uint8_t> keys;
+    std::vector<uint64_t> offsets;
+    std::vector<uint64_t> counts;
+};
+
+// ------------------------------------------------------------------------------------------------
+// parameter derivation
+// ------------------------------------------------------------------------------------------------
+// align_threshold_preflight (lib.rs:100-110): Ok(false) for (0,1), Ok(true) for 1, else ValueError
+static int preflight(double t, bool *skip) {
+    if (t > 0. && t < 1.) { *skip = false; return VF_OK; }
+    if (t == 1.) { *skip = true; return VF_OK; }
+    return fail(VF_EINVAL, "Accept alignment threshold must be between 0 and 1.");
+}
+// lib.rs:260-261 then the strict '>' of lib.rs:157 as an integer bound
+static int64_t int_threshold(double accept, int32_t match, size_t len) {
+    const double min_score = accept * (double)match * (double)len;   // left to right
+    const double f = std::floor(min_score);
+    if (f >= 9.0e15) return INT64_MAX;
+    if (f <= -9.0e15) return INT64_MIN + 1;
+    return (int64_t)f + 1;
+}
+
+static bool pure_acgt(const std::string &s) {
+    for (unsigned char c : s) if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return false;
+    return true;
+}
+static uint64_t pack_adapter(const std::string &s) {
+    uint64_t v = 0;
+    for (size_t i = 0; i < s.size(); ++i) v |= (uint64_t)(g_code[(unsigned char)s[i]] & 3u) << (2 * i);
+    return v;
+}
+static void fill_dp(DpParams &d, const std::string &ad, int64_t T, const vf_ctx &c, bool is_prefix) {
+    d.pat = pack_adapter(ad);
+    d.m = (uint32_t)ad.size();
+    for (int k = 0; k < 4; ++k) d.eq[k] = 0;
+    for (size_t i = 0; i < ad.size(); ++i) d.eq[g_code[(unsigned char)ad[i]] & 3u] |= 1u << i;
+    d.T = (int32_t)std::max<int64_t>(std::min<int64_t>(T, INT32_MAX), INT32_MIN + 1);
+    d.mismatch = c.mismatch;
+    const int32_t S = 1 << kScoreShift, P = 1 << kPrefShift;
+    d.e_open_k = -c.gopen * S - 6 * P + 1;                    // H(pref 6) -> pref 0, len+1
+    d.e_ext_k = -c.gext * S + 1 * P + 1;                      // E(pref 0) -> pref 1, len+1
+    d.f_open_k = -(c.gopen + c.mismatch) * S - 2 * P;          // H(pref 6) -> pref 4, row bias
+    d.f_ext_k = -(c.gext + c.mismatch) * S;                    // F(pref 5) stays 5, row bias
+    d.delta = (uint32_t)(c.match - c.mismatch) << kScoreShift;
+    d.pref_clear = ~kPrefMask;
+    d.pref6 = 6u << kPrefShift;
+    d.is_prefix = is_prefix ? 1u : 0u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// create / destroy
+// ------------------------------------------------------------------------------------------------
+static int table_clear_locked(vf_ctx *c) {
+    HIP_TRY(hipMemsetAsync(c->t_tags.p, 0, c->table_slots * sizeof(uint32_t), c->main_stream));
+    HIP_TRY(hipMemsetAsync(c->t_refs.p, 0, c->table_slots * sizeof(uint64_t), c->main_stream));
+    HIP_TRY(hipMemsetAsync(c->t_counts.p, 0, c->table_slots * sizeof(uint64_t), c->main_stream));
+    HIP_TRY(hipMemsetAsync(c->t_counters.p, 0, C_NUM * sizeof(uint64_t), c->main_stream));
+    HIP_TRY(hipStreamSynchronize(c->main_stream));
+    return VF_OK;
+}
+
+extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
+    std::call_once(g_code_once, init_code);
+    if (!p || !out) return fail(VF_EINVAL, "null argument");
+    *out = nullptr;
+    if ((p->prefix_len && !p->prefix) || (p->suffix_len && !p->suffix)) return fail(VF_EINVAL, "null adapter");
+    std::unique_ptr<vf_ctx> c(new vf_ctx);
+    // prefix threshold is validated first (lib.rs:239), then suffix (lib.rs:249)
+    int rc;
+    if ((rc = preflight(p->accept_prefix_alignment, &c->skip_pre))) return rc;
+    if ((rc = preflight(p->accept_suffix_alignment, &c->skip_suf))) return rc;
+    c->pre.assign((const char *)p->prefix, p->prefix_len);
+    c->suf.assign((const char *)p->suffix, p->suffix_len);
+    c->match = p->match_score; c->mismatch = p->mismatch_score;
+    c->gopen = p->gap_open_penalty; c->gext = p->gap_extend_penalty;
+    c->T_pre = int_threshold(p->accept_prefix_alignment, p->match_score, c->pre.size());
+    c->T_suf = int_threshold(p->accept_suffix_alignment, p->match_score, c->suf.size());
+    c->skip_translation = p->skip_translation != 0;
+    c->n_threads = p->n_threads ? p->n_threads : 3;
+    c->queue_len = std::min<uint32_t>(std::max<uint32_t>(p->queue_len, 1), 16);
+    c->batch_reads = p->batch_reads ? p->batch_reads : (1u << 18);
+    c->dev = p->device;
+
+    // can the 2-bit fast path hold these adapters and scores?  (else every read goes byte-wise)
+    auto small = [](int32_t v) { return v >= -127 && v <= 127; };
+    c->fast_ok = !c->pre.empty() && !c->suf.empty() && c->pre.size() <= (size_t)kMaxFastAdapter &&
+                 c->suf.size() <= (size_t)kMaxFastAdapter && pure_acgt(c->pre) && pure_acgt(c->suf) && small(c->match) &&
+                 small(c->mismatch) && c->gopen >= 0 && c->gopen <= 127 && c->gext >= 0 && c->gext <= 127 &&
+                 c->match >= c->mismatch;
+
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(VF_EDEVICE, "no HIP device visible: the HIP path is required (no CPU fallback)");
+    if (c->dev < 0 || c->dev >= ndev) return fail(VF_EINVAL, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(c->dev));
+    HIP_TRY(hipStreamCreateWithFlags(&c->main_stream, hipStreamNonBlocking));
+
+    // adapters on the device (byte-wise kernel)
+    const size_t alen = c->pre.size() + c->suf.size();
+    if ((rc = c->d_adapters.ensure(alen + 16))) return rc;
+    if (!c->pre.empty()) HIP_TRY(hipMemcpy(c->d_adapters.p, c->pre.data(), c->pre.size(), hipMemcpyHostToDevice));
+    if (!c->suf.empty()) HIP_TRY(hipMemcpy(c->d_adapters.p + c->pre.size(), c->suf.data(), c->suf.size(), hipMemcpyHostToDevice));
+    c->gp.pre = c->d_adapters.p; c->gp.suf = c->d_adapters.p + c->pre.size();
+    c->gp.pre_len = (uint32_t)c->pre.size(); c->gp.suf_len = (uint32_t)c->suf.size();
+    c->gp.align_pre = c->skip_pre ? 0 : 1; c->gp.align_suf = c->skip_suf ? 0 : 1;
+    c->gp.T_pre = c->T_pre; c->gp.T_suf = c->T_suf;
+    c->gp.match = c->match; c->gp.mismatch = c->mismatch; c->gp.open = c->gopen; c->gp.ext = c->gext;
+    c->gp.skip_translation = c->skip_translation ? 1 : 0;
+    c->gp.count_mode = 1;
+    if (c->fast_ok) {
+        c->sp.pre_pat = pack_adapter(c->pre); c->sp.suf_pat = pack_adapter(c->suf);
+        c->sp.pre_len = (uint32_t)c->pre.size(); c->sp.suf_len = (uint32_t)c->suf.size();
+        c->sp.align_pre = c->skip_pre ? 0 : 1; c->sp.align_suf = c->skip_suf ? 0 : 1;
+        fill_dp(c->dpP, c->pre, c->T_pre, *c, true);
+        fill_dp(c->dpS, c->suf, c->T_suf, *c, false);
+    }
+
+    // count table
+    uint64_t slots = p->table_slots ? p->table_slots : (1ull << 24);
+    uint64_t pow2 = 1; while (pow2 < slots) pow2 <<= 1;
+    if (pow2 > (1ull << 32)) return fail(VF_EINVAL, "table_slots too large");
+    c->table_slots = pow2;
+    c->arena_dwords = (p->arena_bytes ? p->arena_bytes : (1ull << 30)) / 4;
+    if ((rc = c->t_tags.ensure(c->table_slots))) return rc;
+    if ((rc = c->t_refs.ensure(c->table_slots))) return rc;
+    if ((rc = c->t_counts.ensure(c->table_slots))) return rc;
+    if ((rc = c->t_arena.ensure(c->arena_dwords))) return rc;
+    if ((rc = c->t_counters.ensure(C_NUM))) return rc;
+    c->tab.tags = c->t_tags.p; c->tab.refs = c->t_refs.p; c->tab.counts = c->t_counts.p;
+    c->tab.arena = c->t_arena.p; c->tab.counters = c->t_counters.p;
+    c->tab.slot_mask = (uint32_t)(c->table_slots - 1); c->tab.arena_cap = c->arena_dwords;
+    if ((rc = table_clear_locked(c.get()))) return rc;
+
+    for (uint32_t i = 0; i < c->queue_len; ++i) {
+        std::unique_ptr<Slot> s(new Slot);
+        HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+        c->slots.push_back(std::move(s));
+    }
+    *out = c.release();
+    return VF_OK;
+}
+
+extern "C" void vf_ctx_destroy(vf_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->dev);
+    (void)hipDeviceSynchronize();
+    for (auto &e : c->pending_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto &s : c->slots) {
+        s->h_rows.release(); s->h_lens.release(); s->d_rows.release(); s->d_lens.release(); s->ws.release();
+        s->h_gbytes.release(); s->h_goffs.release(); s->d_gbytes.release(); s->d_goffs.release();
+        s->d_gstart.release(); s->d_gend.release(); s->d_gws.release(); s->h_gstart.release(); s->h_gend.release();
+        s->h_spans.release();
+        if (s->done) (void)hipEventDestroy(s->done);
+        if (s->stream) (void)hipStreamDestroy(s->stream);
+    }
+    c->resident.release(); c->exp_refs.release(); c->exp_counts.release();
+    c->t_tags.release(); c->t_refs.release(); c->t_counts.release(); c->t_arena.release(); c->t_counters.release();
+    c->d_adapters.release();
+    if (c->main_stream) (void)hipStreamDestroy(c->main_stream);
+    delete c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiling events
+// ------------------------------------------------------------------------------------------------
+static int resolve_events(vf_ctx *c) {
+    std::lock_guard<std::mutex> g(c->ev_mu);
+    for (auto &e : c->pending_events) {
+        float ms = 0.f;
+        hipError_t r = hipEventSynchronize(e.b);
+        if (r == hipSuccess) r = hipEventElapsedTime(&ms, e.a, e.b);
+        if (r == hipSuccess) { c->ms[e.kind] += ms; c->launches[e.kind]++; }
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    c->pending_events.clear();
+    return VF_OK;
+}
+struct Timed {
+    vf_ctx *c; hipStream_t s; int kind; hipEvent_t a = nullptr, b = nullptr; bool on;
+    Timed(vf_ctx *c_, hipStream_t s_, int k) : c(c_), s(s_), kind(k), on(c_->profiling) {
+        if (on) {
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            (void)hipEventRecord(a, s);
+        }
+    }
+    ~Timed() {
+        if (on) {
+            (void)hipEventRecord(b, s);
+            std::lock_guard<std::mutex> g(c->ev_mu);
+            c->pending_events.push_back({a, b, kind});
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// device path over one packed batch (rows/lens already in HBM)
+// ------------------------------------------------------------------------------------------------
+static int run_packed(vf_ctx *c, hipStream_t st, Workspace &ws, const uint32_t *d_rows, int W, const uint16_t *d_lens,
+                      uint64_t n, short2 *d_spans, bool count) {
+    if (n == 0) return VF_OK;
+    if (n > 0xFFFFFFF0ull) return fail(VF_EINVAL, "batch too large (max 2^32-16 reads per submission)");
+    BatchLists bl{ws.listP.p, ws.listS.p, ws.cnt.p};
+    HIP_TRY(hipMemsetAsync(ws.cnt.p, 0, 4 * sizeof(uint32_t), st));
+    { Timed t(c, st, K_SCAN); HIP_TRY(launch_scan(st, W, d_rows, d_lens, n, c->sp, d_spans, bl)); }
+    if (!c->skip_pre) { Timed t(c, st, K_DPP); HIP_TRY(launch_dp(st, W, d_rows, d_lens, n, bl.listP, bl.cnt + 0, c->dpP, d_spans, bl.listS, bl.cnt + 1, c->tab.counters)); }
+    if (!c->skip_suf) { Timed t(c, st, K_DPS); HIP_TRY(launch_dp(st, W, d_rows, d_lens, n, bl.listS, bl.cnt + 1, c->dpS, d_spans, nullptr, nullptr, c->tab.counters)); }
+    if (count) { Timed t(c, st, K_FIN); HIP_TRY(launch_finish(st, W, d_rows, d_lens, n, d_spans, c->skip_translation ? 1 : 0, c->tab)); }
+    return VF_OK;
+}
+
+// generic (byte-wise) batch already staged in slot pinned buffers
+static int run_generic(vf_ctx *c, Slot &s, uint64_t ng, uint64_t nbytes, uint32_t max_len, bool count, bool want_spans) {
+    if (ng == 0) return VF_OK;
+    int rc;
+    if ((rc = s.d_gbytes.ensure(nbytes + 16))) return rc;
+    if ((rc = s.d_goffs.ensure(ng + 1))) return rc;
+    HIP_TRY(hipMemcpyAsync(s.d_gbytes.p, s.h_gbytes.p, nbytes, hipMemcpyHostToDevice, s.stream));
+    HIP_TRY(hipMemcpyAsync(s.d_goffs.p, s.h_goffs.p, (ng + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s.stream));
+    const uint32_t mmax = (uint32_t)std::max(c->pre.size(), c->suf.size());
+    const uint32_t rows = 4 * mmax + (max_len + 3) / 4 + 4;
+    uint64_t threads = std::min<uint64_t>((ng + 255) / 256 * 256, 65536);
+    if ((rc = s.d_gws.ensure((size_t)rows * threads))) return rc;
+    int32_t *ds = nullptr, *de = nullptr;
+    if (want_spans) {
+        if ((rc = s.d_gstart.ensure(ng))) return rc;
+        if ((rc = s.d_gend.ensure(ng))) return rc;
+        ds = s.d_gstart.p; de = s.d_gend.p;
+    }
+    GenericParams gp = c->gp;
+    gp.count_mode = count ? 1 : 0;
+    { Timed t(c, s.stream, K_GEN); HIP_TRY(launch_generic(s.stream, s.d_gbytes.p, s.d_goffs.p, ng, gp, ds, de, s.d_gws.p, threads, rows, c->tab)); }
+    return VF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// slots
+// ------------------------------------------------------------------------------------------------
+static Slot *acquire_slot(vf_ctx *c) {
+    std::unique_lock<std::mutex> lk(c->mu);
+    Slot *s = nullptr;
+    c->cv.wait(lk, [&] {
+        for (auto &x : c->slots) if (!x->busy) { s = x.get(); return true; }
+        return false;
+    });
+    s->busy = true;
+    return s;
+}
+static void release_slot(vf_ctx *c, Slot *s) {
+    { std::lock_guard<std::mutex> g(c->mu); s->busy = false; }
+    c->cv.notify_one();
+}
+static int wait_slot(Slot *s) {
+    if (s->in_flight) {
+        HIP_TRY(hipEventSynchronize(s->done));
+        s->in_flight = false;
+    }
+    return VF_OK;
+}
+
+// classify + pack one chunk into a slot and enqueue it.  spans_out != nullptr => synchronous,
+// spans-only mode (vf_spans_ascii).
+static int submit_chunk(vf_ctx *c, const uint8_t *base, const ReadRef *reads, uint64_t n, int32_t *starts_out, int32_t *ends_out) {
+    if (n == 0) return VF_OK;
+    HIP_TRY(hipSetDevice(c->dev));
+    const bool spans_mode = starts_out != nullptr;
+    Slot *s = acquire_slot(c);
+    struct Rel { vf_ctx *c; Slot *s; ~Rel() { release_slot(c, s); } } rel{c, s};
+    int rc;
+    if ((rc = wait_slot(s))) return rc;
+
+    // geometry of the fast part
+    uint32_t max_fast = 0;
+    if (c->fast_ok)
+        for (uint64_t i = 0; i < n; ++i) if (reads[i].len <= (uint32_t)kMaxFastRead) max_fast = std::max(max_fast, reads[i].len);
+    const uint32_t W = c->fast_ok ? std::max(vf_row_dwords_for(max_fast), 10u) : 0;
+    if (W) {
+        if ((rc = s->h_rows.ensure((size_t)n * W))) return rc;
+        if ((rc = s->h_lens.ensure(n))) return rc;
+    }
+    s->fast_idx.clear(); s->gen_idx.clear();
+    uint64_t nf = 0, ng = 0, gbytes = 0;
+    uint32_t gmax = 0;
+    // generic staging is sized for the worst case lazily: first pass packs, failures are appended
+    std::vector<uint64_t> gen_list;
+    for (uint64_t i = 0; i < n; ++i) {
+        const ReadRef &r = reads[i];
+        bool fast = W && r.len <= (uint32_t)kMaxFastRead;
+        if (fast) fast = vf_pack_read(base + r.off, r.len, s->h_rows.p + nf * W, W) == 0;
+        if (fast) {
+            s->h_lens.p[nf] = (uint16_t)r.len;
+            if (spans_mode) s->fast_idx.push_back((uint32_t)i);
+            ++nf;
+        } else {
+            gen_list.push_back(i);
+            gbytes += r.len;
+            gmax = std::max(gmax, r.len);
+        }
+    }
+    ng = gen_list.size();
+    if (ng) {
+        if ((rc = s->h_gbytes.ensure(gbytes + 16))) return rc;
+        if ((rc = s->h_goffs.ensure(ng + 1))) return rc;
+        uint64_t top = 0;
+        for (uint64_t k = 0; k < ng; ++k) {
+            const ReadRef &r = reads[gen_list[k]];
+            memcpy(s->h_gbytes.p + top, base + r.off, r.len);
+            s->h_goffs.p[k] = top;
+            top += r.len;
+            if (spans_mode) s->gen_idx.push_back((uint32_t)gen_list[k]);
+        }
+        s->h_goffs.p[ng] = top;
+    }
+    c->n_reads += n;
+    c->n_generic += ng;
+
+    if (nf) {
+        if ((rc = s->d_rows.ensure((size_t)nf * W))) return rc;
+        if ((rc = s->d_lens.ensure(nf))) return rc;
+        if ((rc = s->ws.ensure(nf))) return rc;
+        HIP_TRY(hipMemcpyAsync(s->d_rows.p, s->h_rows.p, (size_t)nf * W * 4, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipMemcpyAsync(s->d_lens.p, s->h_lens.p, nf * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
+        if ((rc = run_packed(c, s->stream, s->ws, s->d_rows.p, (int)W, s->d_lens.p, nf, s->ws.spans.p, !spans_mode))) return rc;
+    }
+    if (ng) {
+        if ((rc = run_generic(c, *s, ng, gbytes, gmax, !spans_mode, spans_mode))) return rc;
+    }
+    if (spans_mode) {
+        if (nf) {
+            if ((rc = s->h_spans.ensure(nf))) return rc;
+            HIP_TRY(hipMemcpyAsync(s->h_spans.p, s->ws.spans.p, nf * sizeof(short2), hipMemcpyDeviceToHost, s->stream));
+        }
+        if (ng) {
+            if ((rc = s->h_gstart.ensure(ng))) return rc;
+            if ((rc = s->h_gend.ensure(ng))) return rc;
+            HIP_TRY(hipMemcpyAsync(s->h_gstart.p, s->d_gstart.p, ng * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipMemcpyAsync(s->h_gend.p, s->d_gend.p, ng * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        for (uint64_t k = 0; k < nf; ++k) {
+            const short2 v = s->h_spans.p[k];
+            starts_out[s->fast_idx[k]] = v.x >= 0 ? v.x : -1;
+            ends_out[s->fast_idx[k]] = v.y >= 0 ? v.y : -1;
+        }
+        for (uint64_t k = 0; k < ng; ++k) {
+            starts_out[s->gen_idx[k]] = s->h_gstart.p[k];
+            ends_out[s->gen_idx[k]] = s->h_gend.p[k];
+        }
+    } else {
+        HIP_TRY(hipEventRecord(s->done, s->stream));
+        s->in_flight = true;
+    }
+    return VF_OK;
+}
+
+static int submit_reads(vf_ctx *c, const uint8_t *base, const ReadRef *reads, uint64_t n, int32_t *starts, int32_t *ends) {
+    for (uint64_t lo = 0; lo < n; lo += c->batch_reads) {
+        const uint64_t m = std::min<uint64_t>(c->batch_reads, n - lo);
+        int rc = submit_chunk(c, base, reads + lo, m, starts ? starts + lo : nullptr, ends ? ends + lo : nullptr);
+        if (rc) return rc;
+    }
+    return VF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// public submission entry points
+// ------------------------------------------------------------------------------------------------
+static int to_refs(const uint64_t *offsets, uint64_t n, std::vector<ReadRef> &out) {
+    out.resize(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        if (offsets[i + 1] < offsets[i]) return fail(VF_EINVAL, "offsets must be non-decreasing");
+        const uint64_t len = offsets[i + 1] - offsets[i];
+        if (len > 0xFFFFFFFFull) return fail(VF_EINVAL, "read longer than 4 GiB");
+        out[i] = ReadRef{offsets[i], (uint32_t)len};
+    }
+    return VF_OK;
+}
+
+extern "C" int vf_submit_ascii(vf_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uint64_t n_reads) {
+    if (!c || (n_reads && (!offsets || (!bytes && offsets[n_reads] != 0)))) return fail(VF_EINVAL, "null argument");
+    std::vector<ReadRef> refs;
+    int rc = to_refs(offsets, n_reads, refs);
+    if (rc) return rc;
+    return submit_reads(c, bytes, refs.data(), n_reads, nullptr, nullptr);
+}
+
+extern "C" int vf_spans_ascii(vf_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uint64_t n_reads, int32_t *starts, int32_t *ends) {
+    if (!c || !starts || !ends || (n_reads && !offsets)) return fail(VF_EINVAL, "null argument");
+    std::vector<ReadRef> refs;
+    int rc = to_refs(offsets, n_reads, refs);
+    if (rc) return rc;
+    return submit_reads(c, bytes, refs.data(), n_reads, starts, ends);
+}
+
+extern "C" int vf_submit_packed(vf_ctx *c, const uint32_t *rows, uint32_t W, const uint16_t *lens, uint64_t n) {
+    if (!c || (n && (!rows || !lens))) return fail(VF_EINVAL, "null argument");
+    if (!c->fast_ok) return fail(VF_EINVAL, "these adapters/scores need the byte-wise path: use vf_submit_ascii");
+    if (W != 10 && W != 20 && W != 40) return fail(VF_EINVAL, "row_dwords must be 10, 20 or 40");
+    HIP_TRY(hipSetDevice(c->dev));
+    for (uint64_t lo = 0; lo < n; lo += c->batch_reads) {
+        const uint64_t m = std::min<uint64_t>(c->batch_reads, n - lo);
+        for (uint64_t i = 0; i < m; ++i) if (lens[lo + i] > W * 16u) return fail(VF_EINVAL, "read length exceeds row");
+        Slot *s = acquire_slot(c);
+        struct Rel { vf_ctx *c; Slot *s; ~Rel() { release_slot(c, s); } } rel{c, s};
+        int rc;
+        if ((rc = wait_slot(s))) return rc;
+        if ((rc = s->h_rows.ensure((size_t)m * W))) return rc;
+        if ((rc = s->h_lens.ensure(m))) return rc;
+        memcpy(s->h_rows.p, rows + lo * W, (size_t)m * W * 4);
+        memcpy(s->h_lens.p, lens + lo, m * sizeof(uint16_t));
+        if ((rc = s->d_rows.ensure((size_t)m * W))) return rc;
+        if ((rc = s->d_lens.ensure(m))) return rc;
+        if ((rc = s->ws.ensure(m))) return rc;
+        HIP_TRY(hipMemcpyAsync(s->d_rows.p, s->h_rows.p, (size_t)m * W * 4, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipMemcpyAsync(s->d_lens.p, s->h_lens.p, m * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
+        if ((rc = run_packed(c, s->stream, s->ws, s->d_rows.p, (int)W, s->d_lens.p, m, s->ws.spans.p, true))) return rc;
+        HIP_TRY(hipEventRecord(s->done, s->stream));
+        s->in_flight = true;
+        c->n_reads += m;
+    }
+    return VF_OK;
+}
+
+extern "C" int vf_process_device_packed(vf_ctx *c, const void *d_rows, uint32_t W, const void *d_lens, uint64_t n, void *d_spans) {
+    if (!c || (n && (!d_rows || !d_lens))) return fail(VF_EINVAL, "null argument");
+    if (!c->fast_ok) return fail(VF_EINVAL, "these adapters/scores need the byte-wise path: use vf_submit_ascii");
+    if (W != 10 && W != 20 && W != 40) return fail(VF_EINVAL, "row_dwords must be 10, 20 or 40");
+    HIP_TRY(hipSetDevice(c->dev));
+    int rc;
+    if ((rc = c->resident.ensure(n))) return rc;
+    short2 *spans = d_spans ? (short2 *)d_spans : c->resident.spans.p;
+    if ((rc = run_packed(c, c->main_stream, c->resident, (const uint32_t *)d_rows, (int)W, (const uint16_t *)d_lens, n, spans, true))) return rc;
+    c->n_reads += n;
+    return VF_OK;
+}
+
+static int check_device_errors(vf_ctx *c, uint64_t *counters_out) {
+    uint64_t h[C_NUM];
+    HIP_TRY(hipMemcpy(h, c->t_counters.p, sizeof(h), hipMemcpyDeviceToHost));
+    if (counters_out) memcpy(counters_out, h, sizeof(h));
+    if (h[C_ERROR] & 1) return fail(VF_ECAPACITY, "device key arena full: raise arena_bytes");
+    if (h[C_ERROR] & 2) return fail(VF_ECAPACITY, "device count table full: raise table_slots");
+    if (h[C_ERROR] & 4) return fail(VF_ECAPACITY, "a variant region exceeds 65535 symbols");
+    return VF_OK;
+}
+
+extern "C" int vf_sync(vf_ctx *c) {
+    if (!c) return fail(VF_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(c->dev));
+    {
+        std::lock_guard<std::mutex> g(c->err_mu);
+        if (c->async_rc) { int rc = c->async_rc; std::string m = c->async_msg; c->async_rc = 0; return fail(rc, m); }
+    }
+    for (auto &s : c->slots) {
+        // a slot is only touched by its owner between acquire/release; here nobody may be submitting
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        s->in_flight = false;
+    }
+    HIP_TRY(hipStreamSynchronize(c->main_stream));
+    resolve_events(c);
+    return check_device_errors(c, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// table: clear / export / merge / finish
+// ------------------------------------------------------------------------------------------------
+extern "C" int vf_table_clear(vf_ctx *c) {
+    if (!c) return fail(VF_EINVAL, "null context");
+    int rc = vf_sync(c);
+    if (rc && rc != VF_ECAPACITY) return rc;
+    return table_clear_locked(c);
+}
+
+static uint64_t blob_bytes(uint64_t n, uint64_t arena_dw) { return 16 + n * 16 + arena_dw * 4; }
+
+extern "C" int vf_table_export_size(vf_ctx *c, uint64_t *nbytes) {
+    if (!c || !nbytes) return fail(VF_EINVAL, "null argument");
+    int rc = vf_sync(c);
+    if (rc) return rc;
+    uint64_t h[C_NUM];
+    if ((rc = check_device_errors(c, h))) return rc;
+    *nbytes = blob_bytes(h[C_ENTRIES], h[C_ARENA_TOP]);
+    return VF_OK;
+}
+
+// blob = {u64 n, u64 arena_dwords, u64 refs[n], u64 counts[n], u32 arena[arena_dwords]}
+extern "C" int vf_table_export(vf_ctx *c, void *d_dst, uint64_t capacity, uint64_t *written) {
+    if (!c || !d_dst) return fail(VF_EINVAL, "null argument");
+    int rc = vf_sync(c);
+    if (rc) return rc;
+    uint64_t h[C_NUM];
+    if ((rc = check_device_errors(c, h))) return rc;
+    const uint64_t n = h[C_ENTRIES], adw = h[C_ARENA_TOP];
+    const uint64_t need = blob_bytes(n, adw);
+    if (capacity < need) return fail(VF_EINVAL, "export buffer too small");
+    uint8_t *dst = (uint8_t *)d_dst;
+    const uint64_t hdr[2] = {n, adw};
+    HIP_TRY(hipMemcpyAsync(dst, hdr, 16, hipMemcpyHostToDevice, c->main_stream));
+    HIP_TRY(hipMemsetAsync(c->t_counters.p + C_EXPORT_N, 0, sizeof(uint64_t), c->main_stream));
+    HIP_TRY(launch_export(c->main_stream, c->tab, (uint64_t *)(dst + 16), (uint64_t *)(dst + 16 + n * 8)));
+    if (adw) HIP_TRY(hipMemcpyAsync(dst + 16 + n * 16, c->t_arena.p, adw * 4, hipMemcpyDeviceToDevice, c->main_stream));
+    HIP_TRY(hipStreamSynchronize(c->main_stream));
+    uint64_t got = 0;
+    HIP_TRY(hipMemcpy(&got, c->t_counters.p + C_EXPORT_N, 8, hipMemcpyDeviceToHost));
+    if (got != n) return fail(VF_EDEVICE, "table export count mismatch");
+    if (written) *written = need;
+    return VF_OK;
+}
+
+extern "C" int vf_table_merge(vf_ctx *c, const void *d_blob, uint64_t nbytes) {
+    if (!c || !d_blob) return fail(VF_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->dev));
+    if (nbytes < 16) return fail(VF_EINVAL, "blob too small");
+    uint64_t hdr[2];
+    HIP_TRY(hipMemcpy(hdr, d_blob, 16, hipMemcpyDeviceToHost));
+    if (blob_bytes(hdr[0], hdr[1]) > nbytes) return fail(VF_EINVAL, "blob truncated");
+    const uint8_t *b = (const uint8_t *)d_blob;
+    HIP_TRY(launch_merge(c->main_stream, c->tab, (const uint64_t *)(b + 16), (const uint64_t *)(b + 16 + hdr[0] * 8),
+                         (const uint32_t *)(b + 16 + hdr[0] * 16), hdr[0]));
+    HIP_TRY(hipStreamSynchronize(c->main_stream));
+    return check_device_errors(c, nullptr);
+}
+
+static bool valid_utf8(const uint8_t *s, size_t n) {
+    size_t i = 0;
+    while (i < n) {
+        const uint8_t ch = s[i];
+        if (ch < 0x80) { ++i; continue; }
+        int len; uint32_t cp;
+        if ((ch & 0xE0) == 0xC0) { len = 2; cp = ch & 0x1F; }
+        else if ((ch & 0xF0) == 0xE0) { len = 3; cp = ch & 0x0F; }
+        else if ((ch & 0xF8) == 0xF0) { len = 4; cp = ch & 0x07; }
+        else return false;
+        if (i + len > n) return false;
+        for (int k = 1; k < len; ++k) { if ((s[i + k] & 0xC0) != 0x80) return false; cp = (cp << 6) | (s[i + k] & 0x3F); }
+        if ((len == 2 && cp < 0x80) || (len == 3 && cp < 0x800) || (len == 4 && (cp < 0x10000 || cp > 0x10FFFF))) return false;
+        if (cp >= 0xD800 && cp <= 0xDFFF) return false;
+        i += len;
+    }
+    return true;
+}
+
+extern "C" int vf_finish(vf_ctx *c, vf_result **out) {
+    if (!c || !out) return fail(VF_EINVAL, "null argument");
+    *out = nullptr;
+    uint64_t nbytes = 0;
+    int rc = vf_table_export_size(c, &nbytes);
+    if (rc) return rc;
+    DevBuf<uint8_t> blob;
+    if ((rc = blob.ensure(nbytes))) return rc;
+    struct Free { DevBuf<uint8_t> &b; ~Free() { b.release(); } } fr{blob};
+    if ((rc = vf_table_export(c, blob.p, nbytes, nullptr))) return rc;
+    std::vector<uint8_t> h(nbytes);
+    HIP_TRY(hipMemcpy(h.data(), blob.p, nbytes, hipMemcpyDeviceToHost));
+    const uint64_t n = ((uint64_t *)h.data())[0];
+    const uint64_t *refs = (const uint64_t *)(h.data() + 16);
+    const uint64_t *cnts = refs + n;
+    const uint32_t *arena = (const uint32_t *)(h.data() + 16 + n * 16);
+    // the row set of the DataFrame (lib.rs:312-316); duplicate strings (possible only if the device
+    // saw a stale table word, see vf_kernels.hip:table_add) are summed here
+    std::unordered_map<std::string, uint64_t> rows;
+    rows.reserve(n * 2 + 1);
+    std::string key;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t ref = refs[i];
+        const uint32_t len = (uint32_t)(ref & 0xFFFF), kind = (uint32_t)((ref >> 16) & 3);
+        const uint32_t *k = arena + (ref >> 24);
+        key.clear();
+        if (kind == kKindPacked) {
+            key.resize(len);
+            for (uint32_t b = 0; b < len; ++b) key[b] = "ACGT"[(k[b >> 4] >> (2 * (b & 15))) & 3u];
+        } else {
+            key.assign((const char *)k, len);
+            // String::from_utf8 guard of lib.rs:295 (peptides are ASCII by construction)
+            if (c->skip_translation && !valid_utf8((const uint8_t *)key.data(), key.size())) continue;
+        }
+        rows[key] += cnts[i];
+    }
+    std::vector<std::pair<const std::string *, uint64_t>> order;
+    order.reserve(rows.size());
+    for (auto &kv : rows) order.emplace_back(&kv.first, kv.second);
+    std::sort(order.begin(), order.end(), [](const auto &a, const auto &b) {
+        if (a.second != b.second) return a.second > b.second;
+        return *a.first < *b.first;
+    });
+    std::unique_ptr<vf_result> r(new vf_result);
+    r->offsets.reserve(order.size() + 1);
+    r->counts.reserve(order.size());
+    uint64_t top = 0;
+    for (auto &o : order) {
+        r->offsets.push_back(top);
+        r->keys.insert(r->keys.end(), o.first->begin(), o.first->end());
+        top += o.first->size();
+        r->counts.push_back(o.second);
+    }
+    r->offsets.push_back(top);
+    *out = r.release();
+    return VF_OK;
+}
+
+extern "C" uint64_t vf_result_rows(const vf_result *r) { return r ? r->counts.size() : 0; }
+extern "C" const uint8_t *vf_result_key_bytes(const vf_result *r) { return r ? r->keys.data() : nullptr; }
+extern "C" const uint64_t *vf_result_key_offsets(const vf_result *r) { return r ? r->offsets.data() : nullptr; }
+extern "C" const uint64_t *vf_result_counts(const vf_result *r) { return r ? r->counts.data() : nullptr; }
+extern "C" void vf_result_free(vf_result *r) { delete r; }
+
+// ------------------------------------------------------------------------------------------------
+// stats
+// ------------------------------------------------------------------------------------------------
+extern "C" int vf_stats_get(vf_ctx *c, vf_stats *o) {
+    if (!c || !o) return fail(VF_EINVAL, "null argument");
+    int rc = vf_sync(c);
+    if (rc && rc != VF_ECAPACITY) return rc;
+    uint64_t h[C_NUM];
+    HIP_TRY(hipMemcpy(h, c->t_counters.p, sizeof(h), hipMemcpyDeviceToHost));
+    memset(o, 0, sizeof(*o));
+    o->reads = c->n_reads; o->reads_generic = c->n_generic;
+    o->dp_prefix = h[C_DP_PREFIX]; o->dp_suffix = h[C_DP_SUFFIX];
+    o->accepted = h[C_ACCEPTED]; o->counted = h[C_COUNTED];
+    o->table_entries = h[C_ENTRIES]; o->arena_dwords = h[C_ARENA_TOP];
+    o->ms_scan = c->ms[K_SCAN]; o->ms_dp_prefix = c->ms[K_DPP]; o->ms_dp_suffix = c->ms[K_DPS];
+    o->ms_finish = c->ms[K_FIN]; o->ms_generic = c->ms[K_GEN];
+    o->launches_scan = c->launches[K_SCAN]; o->launches_dp_prefix = c->launches[K_DPP];
+    o->launches_dp_suffix = c->launches[K_DPS]; o->launches_finish = c->launches[K_FIN];
+    o->launches_generic = c->launches[K_GEN];
+    return VF_OK;
+}
+extern "C" int vf_stats_reset(vf_ctx *c) {
+    if (!c) return fail(VF_EINVAL, "null context");
+    int rc = vf_sync(c);
+    if (rc && rc != VF_ECAPACITY) return rc;
+    c->n_reads = 0; c->n_generic = 0;
+    for (int k = 0; k < K_KINDS; ++k) { c->ms[k] = 0; c->launches[k] = 0; }
+    const uint64_t z[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(c->t_counters.p + C_ACCEPTED, z, 4 * sizeof(uint64_t), hipMemcpyHostToDevice));
+    return VF_OK;
+}
+extern "C" int vf_set_profiling(vf_ctx *c, int on) {
+    if (!c) return fail(VF_EINVAL, "null context");
+    c->profiling = on != 0;
+    return VF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gzip FASTQ input (lib.rs:233-234): one inflating reader thread cuts the text into chunks of whole
+// records; n_threads workers frame the records, pack and submit
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Chunk { std::vector<uint8_t> text; size_t used = 0; };
+
+struct ChunkQueue {
+    std::mutex mu;
+    std::condition_variable cv_put, cv_get;
+    std::deque<std::unique_ptr<Chunk>> q;
+    size_t limit;
+    bool closed = false;
+    explicit ChunkQueue(size_t lim) : limit(lim) {}
+    void put(std::unique_ptr<Chunk> c) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_put.wait(lk, [&] { return q.size() < limit || closed; });
+        if (closed) return;
+        q.push_back(std::move(c));
+        cv_get.notify_one();
+    }
+    std::unique_ptr<Chunk> get() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_get.wait(lk, [&] { return !q.empty() || closed; });
+        if (q.empty()) return nullptr;
+        auto c = std::move(q.front());
+        q.pop_front();
+        cv_put.notify_one();
+        return c;
+    }
+    void close() {
+        { std::lock_guard<std::mutex> g(mu); closed = true; }
+        cv_get.notify_all(); cv_put.notify_all();
+    }
+    void abort() {
+        { std::lock_guard<std::mutex> g(mu); closed = true; q.clear(); }
+        cv_get.notify_all(); cv_put.notify_all();
+    }
+};
+
+static void set_async_error(vf_ctx *c, int rc, const std::string &msg) {
+    std::lock_guard<std::mutex> g(c->err_mu);
+    if (!c->async_rc) { c->async_rc = rc; c->async_msg = msg; }
+}
+
+// frames strict four-line records in text[0..n); every record must be complete
+static int frame_records(const uint8_t *t, size_t n, std::vector<ReadRef> &out, std::string &err) {
+    size_t p = 0;
+    auto line_end = [&](size_t from) -> size_t {
+        const void *q = memchr(t + from, '\n', n - from);
+        return q ? (size_t)((const uint8_t *)q - t) : n;
+    };
+    while (p < n) {
+        const size_t e1 = line_end(p);
+        if (e1 == p || (e1 == p + 1 && t[p] == '\r')) {            // blank line: only legal as trailing padding
+            size_t k = p;
+            while (k < n && (t[k] == '\n' || t[k] == '\r')) ++k;
+            if (k == n) return VF_OK;
+            err = "malformed FASTQ: blank line inside the file";
+            return VF_EFORMAT;
+        }
+        if (t[p] != '@') { err = "malformed FASTQ: record does not start with '@'"; return VF_EFORMAT; }
+        if (e1 >= n) { err = "malformed FASTQ: truncated record"; return VF_EFORMAT; }
+        const size_t s2 = e1 + 1, e2 = line_end(s2);
+        if (e2 >= n) { err = "malformed FASTQ: truncated record"; return VF_EFORMAT; }
+        size_t sl = e2 - s2;
+        if (sl && t[e2 - 1] == '\r') --sl;
+        const size_t s3 = e2 + 1, e3 = line_end(s3);
+        if (e3 >= n || s3 >= n || t[s3] != '+') { err = "malformed FASTQ: missing '+' separator line"; return VF_EFORMAT; }
+        const size_t s4 = e3 + 1, e4 = line_end(s4);
+        size_t ql = e4 - s4;
+        if (ql && t[e4 - 1] == '\r') --ql;
+        if (ql != sl) { err = "malformed FASTQ: sequence and quality lengths differ"; return VF_EFORMAT; }
+        if (sl > 0xFFFFFFFFull) { err = "read too long"; return VF_EFORMAT; }
+        out.push_back(ReadRef{(uint64_t)s2, (uint32_t)sl});
+        p = e4 < n ? e4 + 1 : n;
+    }
+    return VF_OK;
+}
+}  // namespace
+
+extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
+    if (!c || !path) return fail(VF_EINVAL, "null argument");
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return fail(VF_EIO, std::string(path) + ": " + strerror(errno));
+    unsigned char magic[2] = {0, 0};
+    const size_t got = fread(magic, 1, 2, fp);
+    fclose(fp);
+    if (got < 2 || magic[0] != 0x1f || magic[1] != 0x8b)
+        return fail(VF_EFORMAT, std::string(path) + ": not a gzip file (the reference reads gzip FASTQ only)");
+    gzFile gz = gzopen(path, "rb");
+    if (!gz) return fail(VF_EIO, std::string(path) + ": gzopen failed");
+    gzbuffer(gz, 1 << 20);
+
+    const size_t kChunk = 16u << 20;
+    ChunkQueue queue(std::max<size_t>(2, c->n_threads));
+    std::atomic<bool> stop{false};
+
+    std::thread reader([&] {
+        std::vector<uint8_t> carry;
+        bool eof = false;
+        while (!eof && !stop.load()) {
+            std::unique_ptr<Chunk> ch(new Chunk);
+            ch->text.resize(carry.size() + kChunk);
+            if (!carry.empty()) memcpy(ch->text.data(), carry.data(), carry.size());
+            size_t fill = carry.size();
+            carry.clear();
+            while (fill < ch->text.size()) {
+                const int r = gzread(gz, ch->text.data() + fill, (unsigned)std::min<size_t>(ch->text.size() - fill, 1u << 30));
+                if (r < 0) {
+                    int en = 0; const char *m = gzerror(gz, &en);
+                    set_async_error(c, VF_EFORMAT, std::string("gzip error: ") + (m ? m : "?"));
+                    stop = true; break;
+                }
+                if (r == 0) { eof = true; break; }
+                fill += (size_t)r;
+            }
+            if (stop.load()) break;
+            // keep whole records: count newlines from the chunk start, cut after the last 4th one
+            size_t cut = 0, lines = 0, pos = 0;
+            const uint8_t *t = ch->text.data();
+            while (pos < fill) {
+                const void *q = memchr(t + pos, '\n', fill - pos);
+                if (!q) break;
+                pos = (size_t)((const uint8_t *)q - t) + 1;
+                if (++lines % 4 == 0) cut = pos;
+            }
+            if (eof) cut = fill;      // the last record may lack a trailing newline
+            carry.assign(t + cut, t + fill);
+            ch->used = cut;
+            if (eof) carry.clear();
+            if (ch->used) queue.put(std::move(ch));
+            else if (!eof && carry.size() > (1u << 30)) { set_async_error(c, VF_EFORMAT, "malformed FASTQ: record larger than 1 GiB"); stop = true; }
+        }
+        if (eof) {
+            int en = 0; (void)gzerror(gz, &en);
+            if (en != Z_OK && en != Z_STREAM_END) set_async_error(c, VF_EFORMAT, "gzip error: truncated or corrupt stream");
+        }
+        queue.close();
+    });
+
+    std::vector<std::thread> workers;
+    for (uint32_t w = 0; w < c->n_threads; ++w) {
+        workers.emplace_back([&] {
+            std::vector<ReadRef> refs;
+            for (;;) {
+                std::unique_ptr<Chunk> ch = queue.get();
+                if (!ch) break;
+                if (stop.load()) continue;
+                refs.clear();
+                std::string err;
+                int rc = frame_records(ch->text.data(), ch->used, refs, err);
+                if (rc) { set_async_error(c, rc, err); stop = true; queue.abort(); break; }
+                rc = submit_reads(c, ch->text.data(), refs.data(), refs.size(), nullptr, nullptr);
+                if (rc) { set_async_error(c, rc, g_err); stop = true; queue.abort(); break; }
+            }
+        });
+    }
+    reader.join();
+    for (auto &t : workers) t.join();
+    gzclose(gz);
+    return vf_sync(c);
+}

@@ -1,0 +1,748 @@
+// vf_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the variant-extraction hot path.
+//
+// One read per lane, 64-lane waves, integer VALU only (no MFMA: there is no dense contraction in
+// this path).  Reference semantics being replaced (vfind 0.3.1, src/lib.rs):
+//   k_scan     memmem::find for both adapters (lib.rs:148) + the control flow of
+//              find_adapter_match (lib.rs:141-166); compacts reads that need the DP by wave ballot
+//   k_dp       parasail sg_stats_scan semi-global affine DP with the `length` statistic
+//              (lib.rs:155-160), tie policy P of SURVEY.md App. B.3
+//   k_finish   seq[start..end] extraction (lib.rs:288-290), translate (lib.rs:16-44) and the
+//              HashMap<String,u64> reduce (lib.rs:292-306) as a device hash-count table
+//   k_generic  the same per-read function byte-wise, for reads/adapters the 2-bit fast path
+//              cannot hold (non-ACGT bytes, adapters > 32 bp, reads > 640 bp, exotic scores)
+//   k_export / k_merge   table compaction and (key,count) merge for the multi-GPU exchange
+#include "vf_device.h"
+
+namespace vf {
+
+#define WAVE 64
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+__device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh) {
+    return __builtin_amdgcn_alignbit(hi, lo, sh);   // (hi:lo >> sh)[31:0], sh in 0..31
+}
+
+template <typename T> __device__ __forceinline__ T ld_agent(const T *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T> __device__ __forceinline__ void st_agent(T *p, T v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wave-aggregated append: returns the slot of this lane in list (valid only if want)
+__device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want) {
+    uint64_t m = __ballot(want);
+    uint32_t total = __popcll(m);
+    uint32_t base = 0;
+    if (total) {
+        uint32_t leader = __ffsll((unsigned long long)m) - 1;
+        if (lane_id() == leader) base = atomicAdd(counter, total);
+        base = __shfl(base, leader);
+    }
+    uint32_t rank = __popcll(m & ((1ull << lane_id()) - 1ull));
+    return base + rank;
+}
+
+__device__ __forceinline__ void wave_count(uint64_t *counter, bool pred) {
+    uint64_t m = __ballot(pred);
+    if (m && lane_id() == (uint32_t)(__ffsll((unsigned long long)m) - 1))
+        atomicAdd((unsigned long long *)counter, (unsigned long long)__popcll(m));
+}
+
+// ------------------------------------------------------------------------------------------------
+// row load: W dwords per read, rows are only 8-byte aligned (W*4 = 40/80/160 bytes)
+// ------------------------------------------------------------------------------------------------
+template <int W> __device__ __forceinline__ void load_row(const uint32_t *rows, uint64_t r, uint32_t (&x)[W + 2]) {
+    const uint2 *p = reinterpret_cast<const uint2 *>(rows + r * W);
+#pragma unroll
+    for (int i = 0; i < W / 2; ++i) {
+        uint2 v = p[i];
+        x[2 * i] = v.x;
+        x[2 * i + 1] = v.y;
+    }
+    x[W] = 0;
+    x[W + 1] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact leftmost search of an m-base pattern in a packed read (memmem::find, lib.rs:148)
+// XOR-accumulate over pattern bases: acc slot p (2 bits) stays 0 iff read[p+j]==pat[j] for all j
+// ------------------------------------------------------------------------------------------------
+template <int W> __device__ __forceinline__ int first_hit(const uint32_t (&acc)[W], int n, int m) {
+    const int limit = n - m + 1;          // number of valid start positions
+    int pos = -1;
+#pragma unroll
+    for (int w = W - 1; w >= 0; --w) {
+        const uint32_t a = acc[w];
+        uint32_t hit = ~(a | (a >> 1)) & 0x55555555u;
+        const int cnt = limit - 16 * w;
+        const uint32_t mask = cnt >= 16 ? 0xFFFFFFFFu : (cnt <= 0 ? 0u : ((1u << (2 * cnt)) - 1u));
+        hit &= mask;
+        if (hit) pos = 16 * w + ((__ffs((int)hit) - 1) >> 1);
+    }
+    return pos;
+}
+
+// both adapters in one pass so the funnel-shifted read words are shared (5 ops per word and base)
+template <int W>
+__device__ __forceinline__ void exact_find2(const uint32_t (&r)[W + 2], int n, const ScanParams &sp, int &ps, int &ss) {
+    uint32_t accP[W], accS[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) { accP[w] = 0; accS[w] = 0; }
+    const int mp = (int)sp.pre_len, ms = (int)sp.suf_len;
+    // pattern bases b and b+16 need the same funnel shift (one word apart): compute it once
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const bool p0 = b < mp, p1 = b + 16 < mp, s0 = b < ms, s1 = b + 16 < ms;     // wave-uniform
+        if (p0 || s0) {
+            uint32_t xs[W + 1];
+#pragma unroll
+            for (int w = 0; w <= W; ++w) xs[w] = b ? funnel(r[w + 1], r[w], 2 * b) : r[w];
+            const uint32_t bp0 = (uint32_t)((sp.pre_pat >> (2 * b)) & 3ull) * 0x55555555u;
+            const uint32_t bp1 = (uint32_t)((sp.pre_pat >> (2 * b + 32)) & 3ull) * 0x55555555u;
+            const uint32_t bs0 = (uint32_t)((sp.suf_pat >> (2 * b)) & 3ull) * 0x55555555u;
+            const uint32_t bs1 = (uint32_t)((sp.suf_pat >> (2 * b + 32)) & 3ull) * 0x55555555u;
+            if (p0) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) accP[w] |= xs[w] ^ bp0;
+            }
+            if (p1) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) accP[w] |= xs[w + 1] ^ bp1;
+            }
+            if (s0) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) accS[w] |= xs[w] ^ bs0;
+            }
+            if (s1) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) accS[w] |= xs[w + 1] ^ bs1;
+            }
+        }
+    }
+    ps = first_hit<W>(accP, n, mp);
+    ss = first_hit<W>(accS, n, ms);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_scan: exact search for both adapters, span bookkeeping, DP work lists
+// ------------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens,
+                                                 uint64_t n_reads, ScanParams sp, short2 *__restrict__ spans,
+                                                 uint32_t *__restrict__ listP, uint32_t *__restrict__ listS,
+                                                 uint32_t *__restrict__ cnt) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t n_round = (n_reads + WAVE - 1) / WAVE * WAVE;
+    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n_round; r += stride) {
+        const bool valid = r < n_reads;
+        uint32_t x[W + 2];
+        int n = 0;
+        if (valid) { load_row<W>(rows, r, x); n = lens[r]; }
+        else {
+#pragma unroll
+            for (int i = 0; i < W + 2; ++i) x[i] = 0;
+        }
+        int ps, ss;
+        exact_find2<W>(x, n, sp, ps, ss);
+        int start = ps >= 0 ? ps + (int)sp.pre_len : (sp.align_pre ? (int)kPending : (int)kNone);
+        int end = ss >= 0 ? ss : ((sp.align_suf && start != kNone) ? (int)kPending : (int)kNone);
+        const bool needP = valid && start == kPending;
+        const bool needS = valid && end == kPending && start >= 0;
+        const uint32_t ip = wave_append(&cnt[0], needP);
+        if (needP) listP[ip] = (uint32_t)r;
+        const uint32_t is = wave_append(&cnt[1], needS);
+        if (needS) listS[is] = (uint32_t)r;
+        if (valid) spans[r] = make_short2((short)start, (short)end);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_dp: semi-global affine-gap DP with the length statistic, one task (read, adapter) per lane.
+// Adapter rows live in VGPRs (Hc/Ec, packed score|pref|len), the read streams in 16 bases a dword.
+// 12 VALU ops per cell; see DESIGN.md for the encoding and the tie-policy argument.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t v_and_or(int32_t x, uint32_t mask_s, int32_t or_v) {
+    int32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(mask_s), "v"(or_v));
+    return r;
+}
+__device__ __forceinline__ int32_t v_mad24(uint32_t bit, uint32_t delta_s, int32_t add_v) {
+    int32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(bit), "s"(delta_s), "v"(add_v));
+    return r;
+}
+
+// M = adapter length, compile-time so the row loop is straight-line code with no register moves
+template <int M>
+__device__ __forceinline__ void dp_align(const uint32_t *__restrict__ row, int n, const DpParams &dp, int &score, int &len) {
+    int32_t Hc[M], Ec[M];
+    const int32_t negv = (int32_t)((uint32_t)kNegScore << kScoreShift);
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        // H[i+1][0] = 0, length 0, biased for row i+1; canonical preference 6
+        Hc[i] = (int32_t)(((uint32_t)(-dp.mismatch * (i + 1)) << kScoreShift) | (6u << kPrefShift) | (uint32_t)(kLenBias - (i + 1)));
+        Ec[i] = negv;
+    }
+    const int32_t v0 = (int32_t)((6u << kPrefShift) | (uint32_t)kLenBias);   // H[0][j] = 0
+    const uint32_t clr = dp.pref_clear;                                       // ~kPrefMask, in an SGPR
+    int32_t pref6 = (int32_t)dp.pref6;                                        // 6<<kPrefShift, in a VGPR
+    asm volatile("" : "+v"(pref6));
+    int32_t best_s = INT32_MIN, best_v = 0;
+    const int nwords = (n + 15) >> 4;
+    uint32_t word_next = nwords > 0 ? row[0] : 0u;
+    for (int w = 0; w < nwords; ++w) {
+        uint32_t word = word_next;
+        if (w + 1 < nwords) word_next = row[w + 1];
+        const int kmax = min(16, n - 16 * w);
+        for (int k = 0; k < kmax; ++k) {
+            const uint32_t c = word & 3u;
+            word >>= 2;
+            const uint32_t eq_lo = (c & 1u) ? dp.eq[1] : dp.eq[0];
+            const uint32_t eq_hi = (c & 1u) ? dp.eq[3] : dp.eq[2];
+            const uint32_t eq = (c & 2u) ? eq_hi : eq_lo;
+            int32_t hdiag = v0, hup = v0, f1 = negv;
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                const int32_t hc = Hc[i], ec = Ec[i];
+                const int32_t e = max(hc + dp.e_open_k, ec + dp.e_ext_k) & (int32_t)~kPrefMask;
+                const int32_t f = max(hup + dp.f_open_k, f1 + dp.f_ext_k) | (int32_t)(1u << kPrefShift);
+                const int32_t d = v_mad24(__builtin_amdgcn_ubfe(eq, i, 1), dp.delta, hdiag);
+                const int32_t h = v_and_or(max(max(d, f), e), clr, pref6);
+                hdiag = hc;
+                Hc[i] = h;
+                Ec[i] = e;
+                hup = h;
+                f1 = f;
+            }
+            // hup is now H[M][j]; strict > keeps the smallest column on ties (policy P3)
+            const int32_t s = hup >> kScoreShift;
+            if (s > best_s) { best_s = s; best_v = hup; }
+        }
+    }
+    if (nwords == 0) { score = INT32_MIN / 2; len = 0; return; }
+    int bscore = best_s + dp.mismatch * M;
+    int blen = (int)((uint32_t)best_v & kLenMask) + M - kLenBias;
+    // last column, rows 1..M-1: replaces only when strictly greater, smallest row on ties
+#pragma unroll
+    for (int i = 0; i < M - 1; ++i) {
+        const int si = (Hc[i] >> kScoreShift) + dp.mismatch * (i + 1);
+        if (si > bscore) { bscore = si; blen = (int)((uint32_t)Hc[i] & kLenMask) + (i + 1) - kLenBias; }
+    }
+    score = bscore;
+    len = blen;
+}
+
+template <int M>
+__global__ __launch_bounds__(kBlock) void k_dp(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
+                                               const uint32_t *__restrict__ list, const uint32_t *__restrict__ count,
+                                               DpParams dp, short2 *__restrict__ spans, uint32_t *__restrict__ listS,
+                                               uint32_t *__restrict__ countS, uint64_t *__restrict__ counters) {
+    const uint32_t ntask = *count;
+    const uint32_t n_round = (ntask + WAVE - 1) / WAVE * WAVE;
+    const uint32_t stride = gridDim.x * kBlock;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        atomicAdd((unsigned long long *)&counters[dp.is_prefix ? C_DP_PREFIX : C_DP_SUFFIX], (unsigned long long)ntask);
+    for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < n_round; t += stride) {
+        const bool valid = t < ntask;
+        uint32_t r = 0;
+        int n = 0;
+        if (valid) { r = list[t]; n = lens[r]; }
+        int score, len;
+        dp_align<M>(rows + (uint64_t)r * W, n, dp, score, len);
+        bool pushS = false;
+        if (valid) {
+            short2 sp = spans[r];
+            const bool ok = score >= dp.T;
+            if (dp.is_prefix) {
+                sp.x = ok ? (short)len : kNone;
+                pushS = ok && sp.y == kPending;
+                if (!ok && sp.y == kPending) sp.y = kNone;
+            } else {
+                sp.y = (ok && len <= n) ? (short)(n - len) : kNone;
+            }
+            spans[r] = sp;
+        }
+        if (dp.is_prefix) {
+            const uint32_t is = wave_append(countS, pushS);
+            if (pushS) listS[is] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// device count table
+// ------------------------------------------------------------------------------------------------
+struct Hash { uint32_t h1, h2; };
+__device__ __forceinline__ void hash_init(Hash &h, uint32_t meta) {
+    h.h1 = 0x811C9DC5u ^ meta;
+    h.h2 = 0x9E3779B9u + meta * 0x85EBCA6Bu;
+}
+__device__ __forceinline__ void hash_step(Hash &h, uint32_t k) {
+    h.h1 = (h.h1 ^ k) * 0x01000193u;
+    h.h2 = (h.h2 + k) * 0x9E3779B1u;
+    h.h2 ^= h.h2 >> 15;
+}
+__device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ void hash_fin(Hash &h) { h.h1 = fmix32(h.h1 ^ (h.h2 >> 7)); h.h2 = fmix32(h.h2) | 1u; }
+
+__device__ __forceinline__ uint32_t key_dwords(uint32_t kind, uint32_t len) {
+    return kind == kKindPacked ? (len + 15u) >> 4 : (len + 3u) >> 2;
+}
+
+// key held in registers (static indexing)
+template <int ND> struct RegKey {
+    const uint32_t (&k)[ND];
+    template <class F> __device__ __forceinline__ void each(uint32_t nd, F f) const {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) if ((uint32_t)d < nd) f((uint32_t)d, k[d]);
+    }
+};
+// key held in memory, element d at p[d*stride]
+struct MemKey {
+    const uint32_t *p;
+    uint64_t stride;
+    template <class F> __device__ __forceinline__ void each(uint32_t nd, F f) const {
+        for (uint32_t d = 0; d < nd; ++d) f(d, p[d * stride]);
+    }
+};
+
+// Adds `cnt` to key's count, inserting the key if absent.  Every word another workgroup may read
+// is written and read with agent-scope (sc1) atomics; write-once words + the publish order
+// tag -> key -> ref mean a stale view can only ever cause a duplicate entry, never a false match
+// (the host merges duplicates when it builds the result).
+template <class K>
+__device__ __forceinline__ void table_add(const Table &t, const K &key, uint32_t kind, uint32_t len, uint64_t cnt, bool active) {
+    const uint32_t nd = key_dwords(kind, len);
+    const uint32_t meta = len | (kind << 16);
+    Hash h;
+    hash_init(h, meta);
+    key.each(nd, [&](uint32_t, uint32_t v) { hash_step(h, v); });
+    hash_fin(h);
+    const uint32_t tag = h.h2;
+    uint32_t slot = h.h1 & t.slot_mask;
+    uint32_t probes = 0;
+    bool done = !active;
+    while (!done) {
+        uint32_t tg = ld_agent(&t.tags[slot]);
+        if (tg == 0u) {
+            const uint32_t old = atomicCAS(&t.tags[slot], 0u, tag);
+            if (old == 0u) {
+                const uint64_t off = atomicAdd((unsigned long long *)&t.counters[C_ARENA_TOP], (unsigned long long)nd);
+                if (off + nd <= t.arena_cap) {
+                    key.each(nd, [&](uint32_t d, uint32_t v) { st_agent(&t.arena[off + d], v); });
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    st_agent(&t.refs[slot], (off << 24) | kRefValid | (uint64_t)meta);
+                } else {
+                    atomicOr((unsigned long long *)&t.counters[C_ERROR], 1ull);
+                    st_agent(&t.refs[slot], kRefOverflow);
+                }
+                atomicAdd((unsigned long long *)&t.counts[slot], (unsigned long long)cnt);
+                atomicAdd((unsigned long long *)&t.counters[C_ENTRIES], 1ull);
+                done = true;
+                continue;
+            }
+            tg = old;
+        }
+        if (tg == tag) {
+            const uint64_t ref = ld_agent(&t.refs[slot]);
+            if (ref == 0ull) continue;                       // claimed, key not yet published: look again
+            if (ref == kRefOverflow) { done = true; continue; }
+            if ((uint32_t)(ref & 0x3FFFFull) == meta) {
+                const uint64_t off = ref >> 24;
+                uint32_t diff = 0;
+                key.each(nd, [&](uint32_t d, uint32_t v) { diff |= ld_agent(&t.arena[off + d]) ^ v; });
+                if (diff == 0u) {
+                    atomicAdd((unsigned long long *)&t.counts[slot], (unsigned long long)cnt);
+                    done = true;
+                    continue;
+                }
+            }
+        }
+        slot = (slot + 1u) & t.slot_mask;
+        if (++probes > t.slot_mask) {
+            atomicOr((unsigned long long *)&t.counters[C_ERROR], 2ull);
+            done = true;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_finish: extract seq[start..end], translate, count
+// ------------------------------------------------------------------------------------------------
+// standard genetic code, index = b0 + 4*b1 + 16*b2 (little-endian codon as it sits in the row)
+__constant__ uint8_t c_codon_le[64];
+
+template <int W>
+__global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens,
+                                                   uint64_t n_reads, const short2 *__restrict__ spans,
+                                                   uint32_t skip_translation, Table t) {
+    constexpr int MAXC = (16 * W) / 3;            // codons a row can hold
+    constexpr int NDA = (MAXC + 3) / 4;           // peptide key dwords
+    __shared__ uint8_t lut[64];
+    if (threadIdx.x < 64) lut[threadIdx.x] = c_codon_le[threadIdx.x];
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t n_round = (n_reads + WAVE - 1) / WAVE * WAVE;
+    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n_round; r += stride) {
+        bool ok = false;
+        int start = 0, end = 0;
+        if (r < n_reads) {
+            const short2 sp = spans[r];
+            start = sp.x; end = sp.y;
+            ok = start >= 0 && end >= 0 && start < end;             // lib.rs:288
+        }
+        wave_count(&t.counters[C_ACCEPTED], ok);
+        if (!__any(ok)) continue;
+        uint32_t x[W + 2];
+        if (ok) load_row<W>(rows, r, x);
+        else {
+#pragma unroll
+            for (int i = 0; i < W + 2; ++i) x[i] = 0;
+        }
+        // shift the row right by `start` bases: word-granular barrel shifter, then bit funnel
+        const uint32_t sh = 2u * (uint32_t)start, ws = sh >> 5, bs = sh & 31u;
+#pragma unroll
+        for (int s = 1; s < W; s <<= 1) {
+            const bool take = (ws & (uint32_t)s) != 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const uint32_t from = w + s < W ? x[w + s] : 0u;
+                x[w] = take ? from : x[w];
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < W; ++w) x[w] = funnel(x[w + 1], x[w], bs);
+        const uint32_t L = ok ? (uint32_t)(end - start) : 0u;
+        if (skip_translation) {
+            // key = the region itself, 2 bits per base (expanded to letters by the host)
+            uint32_t key[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const int rem = (int)L - 16 * w;
+                const uint32_t mask = rem >= 16 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (2 * rem)) - 1u));
+                key[w] = x[w] & mask;
+            }
+            wave_count(&t.counters[C_COUNTED], ok);
+            table_add(t, RegKey<W>{key}, kKindPacked, L, 1ull, ok);
+        } else {
+            const bool tr = ok && (L % 3u) == 0u;                    // lib.rs:17-19
+            const uint32_t nc = tr ? L / 3u : 0u;
+            uint32_t key[NDA];
+#pragma unroll
+            for (int d = 0; d < NDA; ++d) {
+                uint32_t kd = 0;
+                if (__any((uint32_t)(4 * d) < nc)) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = 4 * d + q;
+                        if (c < MAXC) {
+                            const int bit = 6 * c, wi = bit >> 5, bo = bit & 31;
+                            const uint32_t cod = (bo <= 26 ? (x[wi] >> bo) : funnel(x[wi + 1], x[wi], bo)) & 63u;
+                            kd |= (uint32_t)lut[cod] << (8 * q);
+                        }
+                    }
+                    const int rem = (int)nc - 4 * d;
+                    const uint32_t mask = rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (8 * rem)) - 1u));
+                    kd &= mask;
+                }
+                key[d] = kd;
+            }
+            wave_count(&t.counters[C_COUNTED], tr);
+            table_add(t, RegKey<NDA>{key}, kKindBytes, nc, 1ull, tr);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_generic: byte-wise restatement of the whole per-read function (any byte, any length)
+// workspace ws[row*stride + thread]: rows 0..4m-1 = H,HL,E,EL; rows 4m.. = key staging
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int g_code(uint8_t c) {
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;
+    }
+}
+__device__ __forceinline__ int g_tr_index(uint8_t c) {
+    if (c == 'U' || c == 'u') return 3;
+    return g_code(c);
+}
+__device__ int64_t g_find_exact(const uint8_t *s, int64_t n, const uint8_t *a, int64_t m) {
+    if (m == 0) return 0;
+    for (int64_t k = 0; k + m <= n; ++k) {
+        int64_t j = 0;
+        while (j < m && s[k + j] == a[j]) ++j;
+        if (j == m) return k;
+    }
+    return -1;
+}
+// returns false when no cell exists (n == 0)
+__device__ bool g_sg(const uint8_t *q, int m, const uint8_t *r, int64_t n, const GenericParams &gp, int32_t *ws,
+                     uint64_t st, int64_t &score, int64_t &len) {
+    if (n <= 0 || m <= 0) return false;
+    const int32_t NEG = INT32_MIN / 4;
+    int32_t *H = ws, *HL = ws + (uint64_t)m * st, *E = ws + 2ull * m * st, *EL = ws + 3ull * m * st;
+    for (int i = 0; i < m; ++i) { H[i * st] = 0; HL[i * st] = 0; E[i * st] = NEG; EL[i * st] = 0; }
+    int32_t best = NEG, bestl = 0;
+    for (int64_t j = 0; j < n; ++j) {
+        const int rc = g_code(r[j]);
+        int32_t hdiag = 0, hldiag = 0, hup = 0, hlup = 0, f = NEG, fl = 0;
+        for (int i = 0; i < m; ++i) {
+            const int32_t hc = H[i * st], hlc = HL[i * st];
+            const int32_t eo = hc - gp.open, ee = E[i * st] - gp.ext;
+            int32_t e, el;
+            if (eo > ee) { e = eo; el = hlc + 1; } else { e = ee; el = EL[i * st] + 1; }
+            const int32_t fo = hup - gp.open, fe = f - gp.ext;
+            if (fo > fe) { f = fo; fl = hlup + 1; } else { f = fe; fl = fl + 1; }
+            const int qc = g_code(q[i]);
+            const int32_t sub = (qc == 4 || rc == 4) ? 0 : (qc == rc ? gp.match : gp.mismatch);
+            const int32_t d = hdiag + sub, dl = hldiag + 1;
+            int32_t h = max(d, max(e, f));
+            const int32_t hl = (h == d) ? dl : ((h == f) ? fl : el);
+            hdiag = hc; hldiag = hlc;
+            H[i * st] = h; HL[i * st] = hl; E[i * st] = e; EL[i * st] = el;
+            hup = h; hlup = hl;
+        }
+        if (hup > best) { best = hup; bestl = hlup; }
+    }
+    for (int i = 0; i < m - 1; ++i)
+        if (H[i * st] > best) { best = H[i * st]; bestl = HL[i * st]; }
+    score = best; len = bestl;
+    return true;
+}
+__device__ int64_t g_adapter_match(const uint8_t *s, int64_t n, const uint8_t *a, int m, uint32_t align, int64_t T,
+                                   const GenericParams &gp, int32_t *ws, uint64_t st, bool is_prefix) {
+    const int64_t k = g_find_exact(s, n, a, m);
+    if (k >= 0) return is_prefix ? k + m : k;
+    if (!align) return -1;
+    int64_t score, len;
+    if (!g_sg(a, m, s, n, gp, ws, st, score, len)) return -1;
+    if (score >= T) {
+        if (is_prefix) return len;
+        return len <= n ? n - len : -1;
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(kBlock) void k_generic(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ offs,
+                                                    uint64_t n_reads, GenericParams gp, int32_t *__restrict__ starts,
+                                                    int32_t *__restrict__ ends, int32_t *__restrict__ ws, uint64_t st,
+                                                    uint32_t ws_rows, Table t) {
+    const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;   // < st by construction
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t n_round = (n_reads + WAVE - 1) / WAVE * WAVE;
+    int32_t *my = ws + tid;
+    const uint32_t mmax = max(gp.pre_len, gp.suf_len);
+    uint32_t *stage = reinterpret_cast<uint32_t *>(my + 4ull * mmax * st);
+    for (uint64_t r = tid; r < n_round; r += stride) {
+        const bool valid = r < n_reads;
+        const uint8_t *s = bytes;
+        int64_t n = 0, a = -1, b = -1;
+        if (valid) {
+            s = bytes + offs[r];
+            n = (int64_t)(offs[r + 1] - offs[r]);
+            a = g_adapter_match(s, n, gp.pre, (int)gp.pre_len, gp.align_pre, gp.T_pre, gp, my, st, true);
+            b = g_adapter_match(s, n, gp.suf, (int)gp.suf_len, gp.align_suf, gp.T_suf, gp, my, st, false);
+            if (starts) { starts[r] = (int32_t)a; ends[r] = (int32_t)b; }
+        }
+        if (!gp.count_mode) continue;
+        const bool ok = valid && a >= 0 && b >= 0 && a < b;
+        wave_count(&t.counters[C_ACCEPTED], ok);
+        const int64_t L = ok ? b - a : 0;
+        const uint8_t *reg = s + (ok ? a : 0);
+        uint32_t kind = kKindBytes, klen = 0;
+        bool ins = false;
+        if (ok && gp.skip_translation) {
+            bool pure = true;
+            for (int64_t i = 0; i < L; ++i) { const uint8_t c = reg[i]; pure = pure && (c == 'A' || c == 'C' || c == 'G' || c == 'T'); }
+            ins = L <= 0xFFFF;      // key length field is 16 bits; longer regions flag an error below
+            if (!ins) atomicOr((unsigned long long *)&t.counters[C_ERROR], 4ull);
+            if (ins && pure) {
+                kind = kKindPacked; klen = (uint32_t)L;
+                for (uint32_t d = 0; d < (klen + 15u) >> 4; ++d) {
+                    uint32_t v = 0;
+                    for (uint32_t q = 0; q < 16 && 16 * d + q < klen; ++q) v |= (uint32_t)g_code(reg[16 * d + q]) << (2 * q);
+                    stage[d * st] = v;
+                }
+            } else if (ins) {
+                kind = kKindBytes; klen = (uint32_t)L;
+                for (uint32_t d = 0; d < (klen + 3u) >> 2; ++d) {
+                    uint32_t v = 0;
+                    for (uint32_t q = 0; q < 4 && 4 * d + q < klen; ++q) v |= (uint32_t)reg[4 * d + q] << (8 * q);
+                    stage[d * st] = v;
+                }
+            }
+        } else if (ok && (L % 3) == 0) {
+            ins = L / 3 <= 0xFFFF;
+            if (!ins) atomicOr((unsigned long long *)&t.counters[C_ERROR], 4ull);
+            if (ins) {
+                kind = kKindBytes; klen = (uint32_t)(L / 3);
+                for (uint32_t d = 0; d < (klen + 3u) >> 2; ++d) {
+                    uint32_t v = 0;
+                    for (uint32_t q = 0; q < 4 && 4 * d + q < klen; ++q) {
+                        const uint8_t *c = reg + 3ull * (4 * d + q);
+                        uint8_t aa = 'X';
+                        if (c[0] < 0x80 && c[1] < 0x80 && c[2] < 0x80) {
+                            const int i0 = g_tr_index(c[0]), i1 = g_tr_index(c[1]), i2 = g_tr_index(c[2]);
+                            if (i0 != 4 && i1 != 4 && i2 != 4) aa = c_codon_le[i0 + 4 * i1 + 16 * i2];
+                        }
+                        v |= (uint32_t)aa << (8 * q);
+                    }
+                    stage[d * st] = v;
+                }
+            }
+        }
+        (void)ws_rows;
+        wave_count(&t.counters[C_COUNTED], ins);
+        table_add(t, MemKey{stage, st}, kind, klen, 1ull, ins);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// table export (compaction) and merge (multi-GPU exchange)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_export(Table t, uint64_t *__restrict__ out_refs, uint64_t *__restrict__ out_counts) {
+    const uint64_t nslots = (uint64_t)t.slot_mask + 1;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t s = (uint64_t)blockIdx.x * kBlock + threadIdx.x; s < nslots; s += stride) {
+        if (t.tags[s] != 0u) {
+            const uint64_t ref = t.refs[s];
+            if (ref != 0ull && ref != kRefOverflow) {
+                const uint64_t i = atomicAdd((unsigned long long *)&t.counters[C_EXPORT_N], 1ull);
+                out_refs[i] = ref;
+                out_counts[i] = t.counts[s];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_merge(Table t, const uint64_t *__restrict__ refs, const uint64_t *__restrict__ counts,
+                                                  const uint32_t *__restrict__ arena, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t n_round = (n + WAVE - 1) / WAVE * WAVE;
+    for (uint64_t e = (uint64_t)blockIdx.x * kBlock + threadIdx.x; e < n_round; e += stride) {
+        const bool valid = e < n;
+        uint64_t ref = 0, cnt = 0;
+        if (valid) { ref = refs[e]; cnt = counts[e]; }
+        const uint32_t len = (uint32_t)(ref & 0xFFFFull), kind = (uint32_t)((ref >> 16) & 3ull);
+        table_add(t, MemKey{arena + (ref >> 24), 1ull}, kind, len, cnt, valid);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static int grid_for(uint64_t n, int per_cu) {
+    uint64_t g = (n + kBlock - 1) / kBlock;
+    const uint64_t cap = 256ull * per_cu;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+static bool g_lut_ready[64];
+static hipError_t ensure_lut() {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 64 && g_lut_ready[dev]) return hipSuccess;
+    static const char std_code[65] = "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF";
+    uint8_t le[64];
+    for (int b0 = 0; b0 < 4; ++b0)
+        for (int b1 = 0; b1 < 4; ++b1)
+            for (int b2 = 0; b2 < 4; ++b2) le[b0 + 4 * b1 + 16 * b2] = (uint8_t)std_code[b0 * 16 + b1 * 4 + b2];
+    e = hipMemcpyToSymbol(HIP_SYMBOL(c_codon_le), le, 64);
+    if (e == hipSuccess && dev < 64) g_lut_ready[dev] = true;
+    return e;
+}
+
+hipError_t launch_scan(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n, const ScanParams &sp,
+                       short2 *spans, BatchLists bl) {
+    if (n == 0) return hipSuccess;
+    const int g = grid_for(n, 8);
+    switch (W) {
+    case 10: hipLaunchKernelGGL(k_scan<10>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, sp, spans, bl.listP, bl.listS, bl.cnt); break;
+    case 20: hipLaunchKernelGGL(k_scan<20>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, sp, spans, bl.listP, bl.listS, bl.cnt); break;
+    case 40: hipLaunchKernelGGL(k_scan<40>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, sp, spans, bl.listP, bl.listS, bl.cnt); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+template <int M>
+static void launch_dp_m(hipStream_t s, int g, const uint32_t *rows, const uint16_t *lens, int W, const uint32_t *list,
+                        const uint32_t *count, const DpParams &dp, short2 *spans, uint32_t *listS, uint32_t *countS,
+                        uint64_t *counters) {
+    hipLaunchKernelGGL(k_dp<M>, dim3(g), dim3(kBlock), 0, s, rows, lens, W, list, count, dp, spans, listS, countS, counters);
+}
+
+hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n_bound, const uint32_t *list,
+                     const uint32_t *count, const DpParams &dp, short2 *spans, uint32_t *listS, uint32_t *countS,
+                     uint64_t *counters) {
+    if (n_bound == 0) return hipSuccess;
+    const int g = grid_for(n_bound, 8);
+#define VF_DP_CASE(M) case M: launch_dp_m<M>(s, g, rows, lens, W, list, count, dp, spans, listS, countS, counters); break;
+    switch (dp.m) {
+        VF_DP_CASE(1) VF_DP_CASE(2) VF_DP_CASE(3) VF_DP_CASE(4) VF_DP_CASE(5) VF_DP_CASE(6) VF_DP_CASE(7) VF_DP_CASE(8)
+        VF_DP_CASE(9) VF_DP_CASE(10) VF_DP_CASE(11) VF_DP_CASE(12) VF_DP_CASE(13) VF_DP_CASE(14) VF_DP_CASE(15) VF_DP_CASE(16)
+        VF_DP_CASE(17) VF_DP_CASE(18) VF_DP_CASE(19) VF_DP_CASE(20) VF_DP_CASE(21) VF_DP_CASE(22) VF_DP_CASE(23) VF_DP_CASE(24)
+        VF_DP_CASE(25) VF_DP_CASE(26) VF_DP_CASE(27) VF_DP_CASE(28) VF_DP_CASE(29) VF_DP_CASE(30) VF_DP_CASE(31) VF_DP_CASE(32)
+    default: return hipErrorInvalidValue;
+    }
+#undef VF_DP_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n, const short2 *spans,
+                         uint32_t skip_translation, Table t) {
+    if (n == 0) return hipSuccess;
+    hipError_t e = ensure_lut();
+    if (e != hipSuccess) return e;
+    const int g = grid_for(n, 8);
+    switch (W) {
+    case 10: hipLaunchKernelGGL(k_finish<10>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, skip_translation, t); break;
+    case 20: hipLaunchKernelGGL(k_finish<20>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, skip_translation, t); break;
+    case 40: hipLaunchKernelGGL(k_finish<40>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, skip_translation, t); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_generic(hipStream_t s, const uint8_t *bytes, const uint64_t *offs, uint64_t n, const GenericParams &gp,
+                          int32_t *starts, int32_t *ends, int32_t *ws, uint64_t ws_stride, uint32_t ws_rows, Table t) {
+    if (n == 0) return hipSuccess;
+    hipError_t e = ensure_lut();
+    if (e != hipSuccess) return e;
+    uint64_t g = (n + kBlock - 1) / kBlock;
+    if (g * kBlock > ws_stride) g = ws_stride / kBlock;
+    if (g < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_generic, dim3((unsigned)g), dim3(kBlock), 0, s, bytes, offs, n, gp, starts, ends, ws, ws_stride, ws_rows, t);
+    return hipGetLastError();
+}
+
+hipError_t launch_export(hipStream_t s, Table t, uint64_t *out_refs, uint64_t *out_counts) {
+    const int g = grid_for((uint64_t)t.slot_mask + 1, 8);
+    hipLaunchKernelGGL(k_export, dim3(g), dim3(kBlock), 0, s, t, out_refs, out_counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge(hipStream_t s, Table t, const uint64_t *refs, const uint64_t *counts, const uint32_t *arena, uint64_t n) {
+    if (n == 0) return hipSuccess;
+    const int g = grid_for(n, 8);
+    hipLaunchKernelGGL(k_merge, dim3(g), dim3(kBlock), 0, s, t, refs, counts, arena, n);
+    return hipGetLastError();
+}
+
+}  // namespace vf
