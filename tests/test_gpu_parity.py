@@ -25,7 +25,7 @@ def _engine(adapters, **kw):
 def _check_spans(reads, adapters, **kw):
     with _engine(adapters, **kw) as e:
         st, en = e.spans(reads)
-    okw = {k: v for k, v in kw.items() if k not in ("batch_reads",)}
+    okw = {k: v for k, v in kw.items() if k not in ("batch_reads", "queue_len")}
     ost, oen = oracle.spans(reads, adapters, **okw)
     bad = np.nonzero((st != ost) | (en != oen))[0]
     assert bad.size == 0, f"first mismatch read {bad[0]}: gpu=({st[bad[0]]},{en[bad[0]]}) oracle=({ost[bad[0]]},{oen[bad[0]]}) {reads[bad[0]]!r}"
@@ -37,10 +37,13 @@ def _check_counts(reads, adapters, **kw):
         e.submit(reads)
         got = e.finish_dict()
         stats = e.stats()
-    okw = {k: v for k, v in kw.items() if k not in ("batch_reads",)}
+    okw = {k: v for k, v in kw.items() if k not in ("batch_reads", "queue_len")}
     want = oracle.count(reads, adapters, **okw)
     assert got == want
-    assert stats["counted"] == sum(want.values())
+    # (keys that are not valid UTF-8 are counted on the device and dropped when the frame is built)
+    assert stats["counted"] >= sum(want.values())
+    if all(max(r, default=0) < 0x80 for r in map(bytes, reads)):
+        assert stats["counted"] == sum(want.values())
     return got
 
 
@@ -51,7 +54,7 @@ def test_reference_fixture_end_to_end(golden_dir):
         rows = list(csv.reader(f))[1:]
     cols = {c: (out[c].to_list() if hasattr(out[c], "to_list") else out[c].to_pylist()) for c in ("sequence", "count")}
     assert list(zip(cols["sequence"], cols["count"])) == [(r[0], int(r[1])) for r in rows] == [("MAGICAL", 4)]
-    names = out.columns if hasattr(out, "columns") else out.column_names
+    names = out.column_names if hasattr(out, "column_names") else out.columns
     assert list(names) == ["sequence", "count"]
 
 

@@ -35,12 +35,14 @@ struct DpParams {
     uint32_t pref_clear; // ~kPrefMask (kept opaque so it stays in an SGPR for v_and_or_b32)
     uint32_t pref6;      // 6 << kPrefShift
     uint32_t is_prefix;
+    uint32_t independent; // 1 = test hook: run the suffix DP even when the prefix failed (lib.rs:278-286)
 };
 
 struct ScanParams {
     uint64_t pre_pat, suf_pat;
     uint32_t pre_len, suf_len;
     uint32_t align_pre, align_suf;   // 1 = semi-global fallback enabled for that adapter
+    uint32_t independent;            // 1 = both adapters searched regardless of the other's outcome
 };
 
 // ---- generic (byte-wise) path ---------------------------------------------------------------

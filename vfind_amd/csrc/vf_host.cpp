@@ -409,9 +409,13 @@ static int run_packed(vf_ctx *c, hipStream_t st, Workspace &ws, const uint32_t *
     if (n > 0xFFFFFFF0ull) return fail(VF_EINVAL, "batch too large (max 2^32-16 reads per submission)");
     BatchLists bl{ws.listP.p, ws.listS.p, ws.cnt.p};
     HIP_TRY(hipMemsetAsync(ws.cnt.p, 0, 4 * sizeof(uint32_t), st));
-    { Timed t(c, st, K_SCAN); HIP_TRY(launch_scan(st, W, d_rows, d_lens, n, c->sp, d_spans, bl)); }
-    if (!c->skip_pre) { Timed t(c, st, K_DPP); HIP_TRY(launch_dp(st, W, d_rows, d_lens, n, bl.listP, bl.cnt + 0, c->dpP, d_spans, bl.listS, bl.cnt + 1, c->tab.counters)); }
-    if (!c->skip_suf) { Timed t(c, st, K_DPS); HIP_TRY(launch_dp(st, W, d_rows, d_lens, n, bl.listS, bl.cnt + 1, c->dpS, d_spans, nullptr, nullptr, c->tab.counters)); }
+    // counting mode skips the suffix alignment of a read whose prefix failed (same table, less work);
+    // the spans test hook keeps the two searches independent, as find_adapter_match is called (lib.rs:278-286)
+    ScanParams sp = c->sp; DpParams dpP = c->dpP, dpS = c->dpS;
+    sp.independent = dpP.independent = dpS.independent = count ? 0u : 1u;
+    { Timed t(c, st, K_SCAN); HIP_TRY(launch_scan(st, W, d_rows, d_lens, n, sp, d_spans, bl)); }
+    if (!c->skip_pre) { Timed t(c, st, K_DPP); HIP_TRY(launch_dp(st, W, d_rows, d_lens, n, bl.listP, bl.cnt + 0, dpP, d_spans, bl.listS, bl.cnt + 1, c->tab.counters)); }
+    if (!c->skip_suf) { Timed t(c, st, K_DPS); HIP_TRY(launch_dp(st, W, d_rows, d_lens, n, bl.listS, bl.cnt + 1, dpS, d_spans, nullptr, nullptr, c->tab.counters)); }
     if (count) { Timed t(c, st, K_FIN); HIP_TRY(launch_finish(st, W, d_rows, d_lens, n, d_spans, c->skip_translation ? 1 : 0, c->tab)); }
     return VF_OK;
 }

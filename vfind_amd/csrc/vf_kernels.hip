@@ -151,9 +151,9 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ ro
         int ps, ss;
         exact_find2<W>(x, n, sp, ps, ss);
         int start = ps >= 0 ? ps + (int)sp.pre_len : (sp.align_pre ? (int)kPending : (int)kNone);
-        int end = ss >= 0 ? ss : ((sp.align_suf && start != kNone) ? (int)kPending : (int)kNone);
+        int end = ss >= 0 ? ss : ((sp.align_suf && (sp.independent || start != kNone)) ? (int)kPending : (int)kNone);
         const bool needP = valid && start == kPending;
-        const bool needS = valid && end == kPending && start >= 0;
+        const bool needS = valid && end == kPending && (sp.independent || start >= 0);
         const uint32_t ip = wave_append(&cnt[0], needP);
         if (needP) listP[ip] = (uint32_t)r;
         const uint32_t is = wave_append(&cnt[1], needS);
@@ -261,8 +261,8 @@ __global__ __launch_bounds__(kBlock) void k_dp(const uint32_t *__restrict__ rows
             const bool ok = score >= dp.T;
             if (dp.is_prefix) {
                 sp.x = ok ? (short)len : kNone;
-                pushS = ok && sp.y == kPending;
-                if (!ok && sp.y == kPending) sp.y = kNone;
+                pushS = !dp.independent && ok && sp.y == kPending;
+                if (!dp.independent && !ok && sp.y == kPending) sp.y = kNone;
             } else {
                 sp.y = (ok && len <= n) ? (short)(n - len) : kNone;
             }
@@ -331,46 +331,65 @@ __device__ __forceinline__ void table_add(const Table &t, const K &key, uint32_t
     uint32_t slot = h.h1 & t.slot_mask;
     uint32_t probes = 0;
     bool done = !active;
-    while (!done) {
-        uint32_t tg = ld_agent(&t.tags[slot]);
-        if (tg == 0u) {
-            const uint32_t old = atomicCAS(&t.tags[slot], 0u, tag);
-            if (old == 0u) {
-                const uint64_t off = atomicAdd((unsigned long long *)&t.counters[C_ARENA_TOP], (unsigned long long)nd);
-                if (off + nd <= t.arena_cap) {
-                    key.each(nd, [&](uint32_t d, uint32_t v) { st_agent(&t.arena[off + d], v); });
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    st_agent(&t.refs[slot], (off << 24) | kRefValid | (uint64_t)meta);
-                } else {
-                    atomicOr((unsigned long long *)&t.counters[C_ERROR], 1ull);
-                    st_agent(&t.refs[slot], kRefOverflow);
-                }
-                atomicAdd((unsigned long long *)&t.counts[slot], (unsigned long long)cnt);
-                atomicAdd((unsigned long long *)&t.counters[C_ENTRIES], 1ull);
-                done = true;
-                continue;
-            }
-            tg = old;
-        }
-        if (tg == tag) {
-            const uint64_t ref = ld_agent(&t.refs[slot]);
-            if (ref == 0ull) continue;                       // claimed, key not yet published: look again
-            if (ref == kRefOverflow) { done = true; continue; }
-            if ((uint32_t)(ref & 0x3FFFFull) == meta) {
-                const uint64_t off = ref >> 24;
-                uint32_t diff = 0;
-                key.each(nd, [&](uint32_t d, uint32_t v) { diff |= ld_agent(&t.arena[off + d]) ^ v; });
-                if (diff == 0u) {
+    // The loop condition is a wave-wide vote: no lane leaves before every lane is done.  A lane that
+    // finds a slot claimed but not yet published simply looks again on the next trip; because the
+    // claiming lane (possibly in this very wave) publishes inside the loop body, before the vote,
+    // the wait cannot deadlock and the compiler cannot sink the publish past the loop exit.
+    while (__any(!done)) {
+        if (!done) {
+            bool advance = false;
+            uint32_t tg = ld_agent(&t.tags[slot]);
+            if (tg == 0u) {
+                const uint32_t old = atomicCAS(&t.tags[slot], 0u, tag);
+                if (old == 0u) {
+                    const uint64_t off = atomicAdd((unsigned long long *)&t.counters[C_ARENA_TOP], (unsigned long long)nd);
+                    if (off + nd <= t.arena_cap) {
+                        key.each(nd, [&](uint32_t d, uint32_t v) { st_agent(&t.arena[off + d], v); });
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        st_agent(&t.refs[slot], (off << 24) | kRefValid | (uint64_t)meta);
+                    } else {
+                        atomicOr((unsigned long long *)&t.counters[C_ERROR], 1ull);
+                        st_agent(&t.refs[slot], kRefOverflow);
+                    }
                     atomicAdd((unsigned long long *)&t.counts[slot], (unsigned long long)cnt);
+                    atomicAdd((unsigned long long *)&t.counters[C_ENTRIES], 1ull);
                     done = true;
-                    continue;
+                }
+                tg = old;
+            }
+            if (!done) {
+                if (tg == tag) {
+                    const uint64_t ref = ld_agent(&t.refs[slot]);
+                    if (ref == 0ull) {
+                        // claimed, key not yet published: look at the same slot again next trip
+                    } else if (ref == kRefOverflow) {
+                        done = true;
+                    } else {
+                        bool same = (uint32_t)(ref & 0x3FFFFull) == meta;
+                        if (same) {
+                            const uint64_t off = ref >> 24;
+                            uint32_t diff = 0;
+                            key.each(nd, [&](uint32_t d, uint32_t v) { diff |= ld_agent(&t.arena[off + d]) ^ v; });
+                            same = diff == 0u;
+                        }
+                        if (same) {
+                            atomicAdd((unsigned long long *)&t.counts[slot], (unsigned long long)cnt);
+                            done = true;
+                        } else {
+                            advance = true;
+                        }
+                    }
+                } else {
+                    advance = true;
+                }
+                if (advance) {
+                    slot = (slot + 1u) & t.slot_mask;
+                    if (++probes > t.slot_mask) {
+                        atomicOr((unsigned long long *)&t.counters[C_ERROR], 2ull);
+                        done = true;
+                    }
                 }
             }
-        }
-        slot = (slot + 1u) & t.slot_mask;
-        if (++probes > t.slot_mask) {
-            atomicOr((unsigned long long *)&t.counters[C_ERROR], 2ull);
-            done = true;
         }
     }
 }
