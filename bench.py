@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s of the variant-extraction hot path on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the whole device path (exact scan -> semi-global DP fallback -> extract ->
+translate -> hash-count, table cleared first) over one batch of synthetic reads resident in HBM.
+Workload at N=1 = BASELINE.json configs[1]: 10 M synthetic 150 bp reads, 20 bp adapters, default
+alignment parameters (SURVEY.md 8d read model: 0.5 % substitutions / 0.05 % indels in the adapters,
+5 % adapter-free reads, Zipf(1.1) variants from a 10^6 library).  With N GPUs every rank runs the
+same per-GPU workload on its own read range (weak scaling, no data-path collective); the final
+(key,count) table merge over RCCL is timed separately and reported as merge_ms.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def b_alg(read_len: int) -> int:
+    """algorithmic bytes per read: packed read in + one 4-byte (start,end) out"""
+    return (2 * read_len + 7) // 8 + 4
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--adapter-len", type=int, default=20)
+    ap.add_argument("--variants", type=int, default=1_000_000)
+    ap.add_argument("--sub-rate", type=float, default=0.005)
+    ap.add_argument("--indel-rate", type=float, default=0.0005)
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0002)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget (core-seconds) of the baseline sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import vfind_amd
+    from vfind_amd import synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    n = args.reads
+    L = args.read_len
+    host_threads = 16 if world == 1 else 8
+    ads = synth.adapters(args.seed, args.adapter_len)
+    gen = synth.Generator(args.seed, ads, read_len=L, n_variants=args.variants, sub_rate=args.sub_rate,
+                          indel_rate=args.indel_rate)
+    t0 = time.perf_counter()
+    rows_h, lens_h = gen.packed(rank * n, n, host_threads)
+    t_gen = time.perf_counter() - t0
+    rows = torch.from_numpy(rows_h).to(dev)
+    lens = torch.from_numpy(lens_h.view(np.int16)).to(dev)
+    del rows_h, lens_h
+    torch.cuda.synchronize(dev)
+
+    slots = 1 << 22
+    while slots < 4 * min(args.variants, n):
+        slots <<= 1
+    eng = vfind_amd.Engine(ads, device=local_rank, table_slots=slots, arena_bytes=1 << 30)
+
+    # ---- parity gate (rank 0): device path == CPU oracle on a sample of the same reads -----------
+    parity = None
+    cpu = None
+    if rank == 0 and not (args.no_parity and args.no_cpu_baseline):
+        from oracle import oracle          # the checker / CPU baseline; never part of the timed GPU path
+        cores = min(os.cpu_count() or 1, 16)          # a 1-GPU box gives this job a 16-core share
+        probe_n = min(n, 50_000)
+        pb, po = gen.ascii(0, probe_n, host_threads)
+        tq = time.perf_counter()
+        want = oracle.count((pb, po), ads, n_threads=cores)
+        probe_dt = max(time.perf_counter() - tq, 1e-4)
+        if not args.no_parity:
+            eng.submit((pb, po))
+            got = eng.finish_dict()
+            parity = got == want
+            if not parity:
+                raise SystemExit("PARITY FAILED: device (sequence,count) table differs from the CPU oracle")
+            eng.clear()
+        if not args.no_cpu_baseline:
+            rate = probe_n / probe_dt                                     # reads/s on all cores
+            sample = int(min(n, max(probe_n, rate * args.cpu_seconds / 1.0)))
+            sb, so = gen.ascii(0, sample, host_threads)
+            best = None
+            for _ in range(2):
+                tq = time.perf_counter()
+                oracle.count((sb, so), ads, n_threads=cores)
+                dt = time.perf_counter() - tq
+                best = dt if best is None else min(best, dt)
+            cpu = {"value": round(sample / best / 1e6, 4), "unit": "M reads/s", "cores": cores, "kind": "port",
+                   "sample": f"first {sample} reads of the same workload, all {cores} host threads, best of 2; "
+                             "CPU restatement of vfind 0.3.1 (reference not buildable: no rustc/parasail)"}
+            del sb, so
+        del pb, po
+    eng.reset_stats()
+
+    def step():
+        eng.clear()
+        eng.process_device(rows.data_ptr(), gen.row_dwords, lens.data_ptr(), n)
+
+    for _ in range(args.warmup):
+        step()
+    eng.sync()
+    eng.reset_stats()
+    eng.set_profiling(True)
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.sync()
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    eng.set_profiling(False)
+    st = eng.stats()
+
+    # ---- final (key,count) merge across GPUs over RCCL (xGMI), timed separately ------------------
+    merge_ms = None
+    counted_local = st["counted"] // max(args.steps, 1)
+    if world > 1:
+        tot = torch.tensor([counted_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        barrier()
+        tm = time.perf_counter()
+        eng.allreduce_table(dst=0)
+        torch.cuda.synchronize(dev)
+        barrier()
+        merge_ms = (time.perf_counter() - tm) * 1e3
+        if rank == 0:
+            keys, offs, cnts = eng.finish_arrays()
+            if int(cnts.sum()) != int(tot.item()):
+                raise SystemExit("MERGE CHECK FAILED: merged counts do not sum to the per-rank totals")
+        t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        elapsed = float(t_el.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * n * args.steps / elapsed / 1e6
+        kern = {
+            "scan": (st["ms_scan"], st["launches_scan"], n * b_alg(L)),
+            "dp_prefix": (st["ms_dp_prefix"], st["launches_dp_prefix"], None),
+            "dp_suffix": (st["ms_dp_suffix"], st["launches_dp_suffix"], None),
+            "finish": (st["ms_finish"], st["launches_finish"], None),
+        }
+        # per-launch algorithmic bytes of the DP kernels: each task reads its packed row (+2-byte
+        # length, 4-byte task index) and writes one 4-byte span; finish: span in + accepted rows in
+        row_b = (2 * L + 7) // 8
+        steps = max(args.steps, 1)
+        kern["dp_prefix"] = (kern["dp_prefix"][0], kern["dp_prefix"][1], st["dp_prefix"] / steps * (row_b + 10))
+        kern["dp_suffix"] = (kern["dp_suffix"][0], kern["dp_suffix"][1], st["dp_suffix"] / steps * (row_b + 10))
+        kern["finish"] = (kern["finish"][0], kern["finish"][1], n * 4 + st["accepted"] / steps * (row_b + 2))
+        dom = max(kern, key=lambda k: kern[k][0])
+        ms_tot, launches, bytes_per_launch = kern[dom]
+        avg_ms = ms_tot / max(launches, 1)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        path_ms = sum(v[0] for v in kern.values()) / steps
+        path_gbps = n * b_alg(L) / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0
+        out = {
+            "metric": "M reads/sec (150 bp, 20 bp adapters)", "value": round(value, 3), "unit": "M reads/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"{n} synthetic {L} bp reads per GPU per step, {args.adapter_len} bp adapters, default "
+                                   "alignment params (BASELINE.json configs[1]), reads resident in HBM",
+                       "reads_per_gpu": n, "read_len": L, "adapter_len": args.adapter_len, "variants": args.variants,
+                       "sub_rate": args.sub_rate, "indel_rate": args.indel_rate, "parallelism": f"read-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+                         "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(bytes_per_launch)},
+            "roofline_path": {"bound": "hbm", "achieved": round(path_gbps, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "frac": round(path_gbps / HBM_PEAK_GBPS, 6), "alg_bytes_per_read": b_alg(L),
+                              "kernel_ms_per_step": {k: round(v[0] / steps, 4) for k, v in kern.items()}},
+            "cpu_baseline": cpu,
+            "parity_gate": parity,
+            "merge_ms": None if merge_ms is None else round(merge_ms, 3),
+            "per_step": {"dp_prefix_tasks": st["dp_prefix"] // steps, "dp_suffix_tasks": st["dp_suffix"] // steps,
+                         "accepted": st["accepted"] // steps, "counted": st["counted"] // steps,
+                         "table_entries": st["table_entries"]},
+            "gen_s": round(t_gen, 2),
+        }
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

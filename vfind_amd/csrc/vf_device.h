@@ -75,7 +75,12 @@ enum Counter : int {        // uint64 counters[] in device memory
     C_NUM = 8
 };
 
+constexpr uint32_t kMaxGrid = 2048;     // every kernel launches at most this many workgroups
+constexpr uint32_t kChunkRows = 17;     // chunk-state rows: 16 batch streams + the main stream
+
 struct Table {
+    unsigned long long *chunk_state;  // [kChunkRows][kMaxGrid] workgroup arena chunks (see arena_alloc)
+    uint32_t chunk_row;               // row of the launching stream
     uint32_t *tags;
     uint64_t *refs;
     uint64_t *counts;
@@ -86,16 +91,17 @@ struct Table {
 };
 
 // ---- launchers (vf_kernels.hip) ---------------------------------------------------------------
-struct BatchLists {        // per in-flight batch
-    uint32_t *listP, *listS;
-    uint32_t *cnt;         // [0]=nP, [1]=nS
+struct BatchLists {        // per in-flight batch; lists are segmented per workgroup of k_scan
+    uint32_t *listP, *listS;   // grid*seg entries each
+    uint32_t *cntP, *cntS;     // grid entries each
+    uint32_t grid, seg;        // from scan_geometry(n)
 };
 
+void scan_geometry(uint64_t n, uint32_t *grid, uint32_t *seg);
 hipError_t launch_scan(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n,
                        const ScanParams &sp, short2 *spans, BatchLists bl);
-hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n_bound,
-                     const uint32_t *list, const uint32_t *count, const DpParams &dp, short2 *spans,
-                     uint32_t *listS, uint32_t *countS, uint64_t *counters);
+hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
+                     short2 *spans, BatchLists bl, uint64_t *counters);
 hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n,
                          const short2 *spans, uint32_t skip_translation, Table t);
 hipError_t launch_generic(hipStream_t s, const uint8_t *bytes, const uint64_t *offs, uint64_t n,

@@ -135,10 +135,12 @@ struct Workspace {               // device scratch of one in-flight batch
     DevBuf<uint32_t> listP, listS, cnt;
     int ensure(size_t n) {
         int rc;
+        uint32_t g, seg;
+        scan_geometry(n, &g, &seg);
         if ((rc = spans.ensure(n))) return rc;
-        if ((rc = listP.ensure(n))) return rc;
-        if ((rc = listS.ensure(n))) return rc;
-        return cnt.ensure(4);
+        if ((rc = listP.ensure((size_t)g * seg))) return rc;
+        if ((rc = listS.ensure((size_t)g * seg))) return rc;
+        return cnt.ensure(2 * 2048);
     }
     void release() { spans.release(); listP.release(); listS.release(); cnt.release(); }
 };
@@ -146,6 +148,7 @@ struct Workspace {               // device scratch of one in-flight batch
 struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
+    uint32_t index = 0;          // chunk-state row of this slot's stream
     bool busy = false;           // owned by a submitting thread
     bool in_flight = false;      // event recorded, not yet waited
     // fast path staging
@@ -183,6 +186,7 @@ struct vf_ctx {
     Table tab{};
     uint64_t table_slots = 0, arena_dwords = 0;
     DevBuf<uint32_t> t_tags; DevBuf<uint64_t> t_refs, t_counts; DevBuf<uint32_t> t_arena; DevBuf<uint64_t> t_counters;
+    DevBuf<unsigned long long> t_chunks;
     // pipeline
     std::vector<std::unique_ptr<Slot>> slots;
     std::mutex mu;
@@ -257,11 +261,13 @@ static void fill_dp(DpParams &d, const std::string &ad, int64_t T, const vf_ctx 
 // ------------------------------------------------------------------------------------------------
 // create / destroy
 // ------------------------------------------------------------------------------------------------
-static int table_clear_locked(vf_ctx *c) {
+static int table_clear_locked(vf_ctx *c, bool all_counters = false) {
     HIP_TRY(hipMemsetAsync(c->t_tags.p, 0, c->table_slots * sizeof(uint32_t), c->main_stream));
     HIP_TRY(hipMemsetAsync(c->t_refs.p, 0, c->table_slots * sizeof(uint64_t), c->main_stream));
     HIP_TRY(hipMemsetAsync(c->t_counts.p, 0, c->table_slots * sizeof(uint64_t), c->main_stream));
-    HIP_TRY(hipMemsetAsync(c->t_counters.p, 0, C_NUM * sizeof(uint64_t), c->main_stream));
+    HIP_TRY(hipMemsetAsync(c->t_chunks.p, 0, (size_t)kChunkRows * kMaxGrid * sizeof(unsigned long long), c->main_stream));
+    // arena top, entry count and error bits belong to the table; the read statistics do not
+    HIP_TRY(hipMemsetAsync(c->t_counters.p, 0, (all_counters ? (size_t)C_NUM : 3) * sizeof(uint64_t), c->main_stream));
     HIP_TRY(hipStreamSynchronize(c->main_stream));
     return VF_OK;
 }
@@ -333,13 +339,16 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     if ((rc = c->t_counts.ensure(c->table_slots))) return rc;
     if ((rc = c->t_arena.ensure(c->arena_dwords))) return rc;
     if ((rc = c->t_counters.ensure(C_NUM))) return rc;
+    if ((rc = c->t_chunks.ensure((size_t)kChunkRows * kMaxGrid))) return rc;
+    c->tab.chunk_state = c->t_chunks.p; c->tab.chunk_row = kChunkRows - 1;
     c->tab.tags = c->t_tags.p; c->tab.refs = c->t_refs.p; c->tab.counts = c->t_counts.p;
     c->tab.arena = c->t_arena.p; c->tab.counters = c->t_counters.p;
     c->tab.slot_mask = (uint32_t)(c->table_slots - 1); c->tab.arena_cap = c->arena_dwords;
-    if ((rc = table_clear_locked(c.get()))) return rc;
+    if ((rc = table_clear_locked(c.get(), true))) return rc;
 
     for (uint32_t i = 0; i < c->queue_len; ++i) {
         std::unique_ptr<Slot> s(new Slot);
+        s->index = i;
         HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
         c->slots.push_back(std::move(s));
@@ -362,7 +371,7 @@ extern "C" void vf_ctx_destroy(vf_ctx *c) {
         if (s->stream) (void)hipStreamDestroy(s->stream);
     }
     c->resident.release(); c->exp_refs.release(); c->exp_counts.release();
-    c->t_tags.release(); c->t_refs.release(); c->t_counts.release(); c->t_arena.release(); c->t_counters.release();
+    c->t_tags.release(); c->t_refs.release(); c->t_counts.release(); c->t_arena.release(); c->t_counters.release(); c->t_chunks.release();
     c->d_adapters.release();
     if (c->main_stream) (void)hipStreamDestroy(c->main_stream);
     delete c;
@@ -403,20 +412,22 @@ struct Timed {
 // ------------------------------------------------------------------------------------------------
 // device path over one packed batch (rows/lens already in HBM)
 // ------------------------------------------------------------------------------------------------
-static int run_packed(vf_ctx *c, hipStream_t st, Workspace &ws, const uint32_t *d_rows, int W, const uint16_t *d_lens,
-                      uint64_t n, short2 *d_spans, bool count) {
+static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &ws, const uint32_t *d_rows, int W,
+                      const uint16_t *d_lens, uint64_t n, short2 *d_spans, bool count) {
     if (n == 0) return VF_OK;
     if (n > 0xFFFFFFF0ull) return fail(VF_EINVAL, "batch too large (max 2^32-16 reads per submission)");
-    BatchLists bl{ws.listP.p, ws.listS.p, ws.cnt.p};
-    HIP_TRY(hipMemsetAsync(ws.cnt.p, 0, 4 * sizeof(uint32_t), st));
+    BatchLists bl{ws.listP.p, ws.listS.p, ws.cnt.p, ws.cnt.p + 2048, 0, 0};
+    scan_geometry(n, &bl.grid, &bl.seg);
     // counting mode skips the suffix alignment of a read whose prefix failed (same table, less work);
     // the spans test hook keeps the two searches independent, as find_adapter_match is called (lib.rs:278-286)
     ScanParams sp = c->sp; DpParams dpP = c->dpP, dpS = c->dpS;
     sp.independent = dpP.independent = dpS.independent = count ? 0u : 1u;
     { Timed t(c, st, K_SCAN); HIP_TRY(launch_scan(st, W, d_rows, d_lens, n, sp, d_spans, bl)); }
-    if (!c->skip_pre) { Timed t(c, st, K_DPP); HIP_TRY(launch_dp(st, W, d_rows, d_lens, n, bl.listP, bl.cnt + 0, dpP, d_spans, bl.listS, bl.cnt + 1, c->tab.counters)); }
-    if (!c->skip_suf) { Timed t(c, st, K_DPS); HIP_TRY(launch_dp(st, W, d_rows, d_lens, n, bl.listS, bl.cnt + 1, dpS, d_spans, nullptr, nullptr, c->tab.counters)); }
-    if (count) { Timed t(c, st, K_FIN); HIP_TRY(launch_finish(st, W, d_rows, d_lens, n, d_spans, c->skip_translation ? 1 : 0, c->tab)); }
+    if (!c->skip_pre) { Timed t(c, st, K_DPP); HIP_TRY(launch_dp(st, W, d_rows, d_lens, dpP, d_spans, bl, c->tab.counters)); }
+    if (!c->skip_suf) { Timed t(c, st, K_DPS); HIP_TRY(launch_dp(st, W, d_rows, d_lens, dpS, d_spans, bl, c->tab.counters)); }
+    Table tab = c->tab;
+    tab.chunk_row = chunk_row;
+    if (count) { Timed t(c, st, K_FIN); HIP_TRY(launch_finish(st, W, d_rows, d_lens, n, d_spans, c->skip_translation ? 1 : 0, tab)); }
     return VF_OK;
 }
 
@@ -440,7 +451,9 @@ static int run_generic(vf_ctx *c, Slot &s, uint64_t ng, uint64_t nbytes, uint32_
     }
     GenericParams gp = c->gp;
     gp.count_mode = count ? 1 : 0;
-    { Timed t(c, s.stream, K_GEN); HIP_TRY(launch_generic(s.stream, s.d_gbytes.p, s.d_goffs.p, ng, gp, ds, de, s.d_gws.p, threads, rows, c->tab)); }
+    Table tab = c->tab;
+    tab.chunk_row = s.index;
+    { Timed t(c, s.stream, K_GEN); HIP_TRY(launch_generic(s.stream, s.d_gbytes.p, s.d_goffs.p, ng, gp, ds, de, s.d_gws.p, threads, rows, tab)); }
     return VF_OK;
 }
 
@@ -531,7 +544,7 @@ static int submit_chunk(vf_ctx *c, const uint8_t *base, const ReadRef *reads, ui
         if ((rc = s->ws.ensure(nf))) return rc;
         HIP_TRY(hipMemcpyAsync(s->d_rows.p, s->h_rows.p, (size_t)nf * W * 4, hipMemcpyHostToDevice, s->stream));
         HIP_TRY(hipMemcpyAsync(s->d_lens.p, s->h_lens.p, nf * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
-        if ((rc = run_packed(c, s->stream, s->ws, s->d_rows.p, (int)W, s->d_lens.p, nf, s->ws.spans.p, !spans_mode))) return rc;
+        if ((rc = run_packed(c, s->stream, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, nf, s->ws.spans.p, !spans_mode))) return rc;
     }
     if (ng) {
         if ((rc = run_generic(c, *s, ng, gbytes, gmax, !spans_mode, spans_mode))) return rc;
@@ -624,7 +637,7 @@ extern "C" int vf_submit_packed(vf_ctx *c, const uint32_t *rows, uint32_t W, con
         if ((rc = s->ws.ensure(m))) return rc;
         HIP_TRY(hipMemcpyAsync(s->d_rows.p, s->h_rows.p, (size_t)m * W * 4, hipMemcpyHostToDevice, s->stream));
         HIP_TRY(hipMemcpyAsync(s->d_lens.p, s->h_lens.p, m * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
-        if ((rc = run_packed(c, s->stream, s->ws, s->d_rows.p, (int)W, s->d_lens.p, m, s->ws.spans.p, true))) return rc;
+        if ((rc = run_packed(c, s->stream, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, m, s->ws.spans.p, true))) return rc;
         HIP_TRY(hipEventRecord(s->done, s->stream));
         s->in_flight = true;
         c->n_reads += m;
@@ -640,7 +653,7 @@ extern "C" int vf_process_device_packed(vf_ctx *c, const void *d_rows, uint32_t 
     int rc;
     if ((rc = c->resident.ensure(n))) return rc;
     short2 *spans = d_spans ? (short2 *)d_spans : c->resident.spans.p;
-    if ((rc = run_packed(c, c->main_stream, c->resident, (const uint32_t *)d_rows, (int)W, (const uint16_t *)d_lens, n, spans, true))) return rc;
+    if ((rc = run_packed(c, c->main_stream, kChunkRows - 1, c->resident, (const uint32_t *)d_rows, (int)W, (const uint16_t *)d_lens, n, spans, true))) return rc;
     c->n_reads += n;
     return VF_OK;
 }

@@ -48,10 +48,10 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool want) {
     return base + rank;
 }
 
-__device__ __forceinline__ void wave_count(uint64_t *counter, bool pred) {
+// wave-aggregated add of popcount(pred) to a workgroup-local (LDS) counter
+__device__ __forceinline__ void wave_count_lds(uint32_t *s_counter, bool pred) {
     uint64_t m = __ballot(pred);
-    if (m && lane_id() == (uint32_t)(__ffsll((unsigned long long)m) - 1))
-        atomicAdd((unsigned long long *)counter, (unsigned long long)__popcll(m));
+    if (m && lane_id() == (uint32_t)(__ffsll((unsigned long long)m) - 1)) atomicAdd(s_counter, (uint32_t)__popcll(m));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -132,13 +132,19 @@ __device__ __forceinline__ void exact_find2(const uint32_t (&r)[W + 2], int n, c
 // ------------------------------------------------------------------------------------------------
 // k_scan: exact search for both adapters, span bookkeeping, DP work lists
 // ------------------------------------------------------------------------------------------------
+// Work lists are segmented per workgroup: block b appends to list[b*seg ..) through a counter in LDS
+// and publishes the count at kernel end, so no global counter is ever contended (a single global
+// append counter serialises ~10 ns per wave and dominated this kernel).
 template <int W>
 __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens,
                                                  uint64_t n_reads, ScanParams sp, short2 *__restrict__ spans,
-                                                 uint32_t *__restrict__ listP, uint32_t *__restrict__ listS,
-                                                 uint32_t *__restrict__ cnt) {
+                                                 BatchLists bl) {
+    __shared__ uint32_t s_cnt[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const uint64_t n_round = (n_reads + WAVE - 1) / WAVE * WAVE;
+    const uint64_t seg0 = (uint64_t)blockIdx.x * bl.seg;
     for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n_round; r += stride) {
         const bool valid = r < n_reads;
         uint32_t x[W + 2];
@@ -154,12 +160,14 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ ro
         int end = ss >= 0 ? ss : ((sp.align_suf && (sp.independent || start != kNone)) ? (int)kPending : (int)kNone);
         const bool needP = valid && start == kPending;
         const bool needS = valid && end == kPending && (sp.independent || start >= 0);
-        const uint32_t ip = wave_append(&cnt[0], needP);
-        if (needP) listP[ip] = (uint32_t)r;
-        const uint32_t is = wave_append(&cnt[1], needS);
-        if (needS) listS[is] = (uint32_t)r;
+        const uint32_t ip = wave_append(&s_cnt[0], needP);
+        if (needP) bl.listP[seg0 + ip] = (uint32_t)r;
+        const uint32_t is = wave_append(&s_cnt[1], needS);
+        if (needS) bl.listS[seg0 + is] = (uint32_t)r;
         if (valid) spans[r] = make_short2((short)start, (short)end);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) { bl.cntP[blockIdx.x] = s_cnt[0]; bl.cntS[blockIdx.x] = s_cnt[1]; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -238,21 +246,23 @@ __device__ __forceinline__ void dp_align(const uint32_t *__restrict__ row, int n
     len = blen;
 }
 
+// block b consumes segment b of its role's list (written by block b of k_scan / of the prefix pass)
 template <int M>
 __global__ __launch_bounds__(kBlock) void k_dp(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
-                                               const uint32_t *__restrict__ list, const uint32_t *__restrict__ count,
-                                               DpParams dp, short2 *__restrict__ spans, uint32_t *__restrict__ listS,
-                                               uint32_t *__restrict__ countS, uint64_t *__restrict__ counters) {
-    const uint32_t ntask = *count;
+                                               DpParams dp, short2 *__restrict__ spans, BatchLists bl,
+                                               uint64_t *__restrict__ counters) {
+    __shared__ uint32_t s_cntS;
+    const uint32_t *list = dp.is_prefix ? bl.listP : bl.listS;
+    const uint32_t ntask = (dp.is_prefix ? bl.cntP : bl.cntS)[blockIdx.x];
+    if (threadIdx.x == 0) s_cntS = bl.cntS[blockIdx.x];
+    __syncthreads();
     const uint32_t n_round = (ntask + WAVE - 1) / WAVE * WAVE;
-    const uint32_t stride = gridDim.x * kBlock;
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        atomicAdd((unsigned long long *)&counters[dp.is_prefix ? C_DP_PREFIX : C_DP_SUFFIX], (unsigned long long)ntask);
-    for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < n_round; t += stride) {
+    const uint64_t seg0 = (uint64_t)blockIdx.x * bl.seg;
+    for (uint32_t t = threadIdx.x; t < n_round; t += kBlock) {
         const bool valid = t < ntask;
         uint32_t r = 0;
         int n = 0;
-        if (valid) { r = list[t]; n = lens[r]; }
+        if (valid) { r = list[seg0 + t]; n = lens[r]; }
         int score, len;
         dp_align<M>(rows + (uint64_t)r * W, n, dp, score, len);
         bool pushS = false;
@@ -269,9 +279,14 @@ __global__ __launch_bounds__(kBlock) void k_dp(const uint32_t *__restrict__ rows
             spans[r] = sp;
         }
         if (dp.is_prefix) {
-            const uint32_t is = wave_append(countS, pushS);
-            if (pushS) listS[is] = r;
+            const uint32_t is = wave_append(&s_cntS, pushS);
+            if (pushS) bl.listS[seg0 + is] = r;
         }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (dp.is_prefix) bl.cntS[blockIdx.x] = s_cntS;
+        if (ntask) atomicAdd((unsigned long long *)&counters[dp.is_prefix ? C_DP_PREFIX : C_DP_SUFFIX], (unsigned long long)ntask);
     }
 }
 
@@ -315,12 +330,59 @@ struct MemKey {
     }
 };
 
-// Adds `cnt` to key's count, inserting the key if absent.  Every word another workgroup may read
-// is written and read with agent-scope (sc1) atomics; write-once words + the publish order
-// tag -> key -> ref mean a stale view can only ever cause a duplicate entry, never a false match
-// (the host merges duplicates when it builds the result).
+// ---- workgroup-local arena allocator ---------------------------------------------------------------
+// New keys take their arena space from a chunk owned by the workgroup; only a chunk refill touches
+// the global bump pointer (a per-key atomicAdd on one address serialised at ~7 ns per new key and
+// dominated k_finish).  The chunk state survives across launches in t.chunk_state[row][block], one
+// row per stream, so the arena loses at most one partial chunk per (stream, workgroup) in total.
+//   state = (chunk_index + 1) << 32 | dwords_used      (0 = no chunk yet)
+constexpr uint32_t kChunk = 4096;            // dwords
+struct BlockTable {
+    unsigned long long chunk;                // LDS copy of the chunk state
+    uint32_t new_entries;                    // keys inserted by this workgroup (flushed at kernel end)
+};
+__device__ __forceinline__ void block_table_begin(BlockTable &bt, const Table &t) {
+    if (threadIdx.x == 0) {
+        bt.chunk = t.chunk_state[(uint64_t)t.chunk_row * kMaxGrid + blockIdx.x];
+        bt.new_entries = 0;
+    }
+}
+__device__ __forceinline__ void block_table_end(BlockTable &bt, const Table &t) {     // after a __syncthreads()
+    if (threadIdx.x == 0) {
+        t.chunk_state[(uint64_t)t.chunk_row * kMaxGrid + blockIdx.x] = bt.chunk;
+        if (bt.new_entries) atomicAdd((unsigned long long *)&t.counters[C_ENTRIES], (unsigned long long)bt.new_entries);
+    }
+}
+enum { kAllocRetry = 0, kAllocOk = 1, kAllocFull = 2 };
+__device__ __forceinline__ int arena_alloc(BlockTable &bt, const Table &t, uint32_t nd, uint64_t &off) {
+    if (nd > kChunk / 4) {                   // oversized key: whole chunks straight from the global pointer
+        const uint64_t span = (uint64_t)(nd + kChunk - 1) / kChunk * kChunk;
+        off = atomicAdd((unsigned long long *)&t.counters[C_ARENA_TOP], (unsigned long long)span);
+        return off + span <= t.arena_cap ? kAllocOk : kAllocFull;
+    }
+    const unsigned long long old = atomicAdd(&bt.chunk, (unsigned long long)nd);
+    const uint32_t used = (uint32_t)old, idxp1 = (uint32_t)(old >> 32);
+    if (idxp1 != 0u && used + nd <= kChunk) { off = (uint64_t)(idxp1 - 1u) * kChunk + used; return kAllocOk; }
+    const bool crosser = idxp1 == 0u ? used == 0u : used <= kChunk;
+    if (!crosser) return kAllocRetry;        // the lane that crossed the chunk end is fetching a new chunk
+    const uint64_t base = atomicAdd((unsigned long long *)&t.counters[C_ARENA_TOP], (unsigned long long)kChunk);
+    if (base + kChunk > t.arena_cap) {
+        atomicExch(&bt.chunk, 0ull);         // let a later lane try again (and fail the same way)
+        return kAllocFull;
+    }
+    atomicExch(&bt.chunk, ((unsigned long long)(base / kChunk + 1u) << 32) | (unsigned long long)nd);
+    off = base;
+    return kAllocOk;
+}
+
+// Finds key's slot, inserting the key if absent; returns kNoSlot on a capacity error.  Every word
+// another workgroup may read is written and read with agent-scope (sc1) atomics; write-once words +
+// the publish order tag -> key -> ref mean a stale view can only ever cause a duplicate entry, never
+// a false match (the host merges duplicates when it builds the result).
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 template <class K>
-__device__ __forceinline__ void table_add(const Table &t, const K &key, uint32_t kind, uint32_t len, uint64_t cnt, bool active) {
+__device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTable &bt, const K &key, uint32_t kind, uint32_t len, bool active) {
+    uint32_t found = kNoSlot;
     const uint32_t nd = key_dwords(kind, len);
     const uint32_t meta = len | (kind << 16);
     Hash h;
@@ -331,6 +393,7 @@ __device__ __forceinline__ void table_add(const Table &t, const K &key, uint32_t
     uint32_t slot = h.h1 & t.slot_mask;
     uint32_t probes = 0;
     bool done = !active;
+    bool claimed = false;                    // this lane won the slot's tag and must publish its key
     // The loop condition is a wave-wide vote: no lane leaves before every lane is done.  A lane that
     // finds a slot claimed but not yet published simply looks again on the next trip; because the
     // claiming lane (possibly in this very wave) publishes inside the loop body, before the vote,
@@ -338,60 +401,91 @@ __device__ __forceinline__ void table_add(const Table &t, const K &key, uint32_t
     while (__any(!done)) {
         if (!done) {
             bool advance = false;
-            uint32_t tg = ld_agent(&t.tags[slot]);
-            if (tg == 0u) {
-                const uint32_t old = atomicCAS(&t.tags[slot], 0u, tag);
-                if (old == 0u) {
-                    const uint64_t off = atomicAdd((unsigned long long *)&t.counters[C_ARENA_TOP], (unsigned long long)nd);
-                    if (off + nd <= t.arena_cap) {
-                        key.each(nd, [&](uint32_t d, uint32_t v) { st_agent(&t.arena[off + d], v); });
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        st_agent(&t.refs[slot], (off << 24) | kRefValid | (uint64_t)meta);
-                    } else {
-                        atomicOr((unsigned long long *)&t.counters[C_ERROR], 1ull);
-                        st_agent(&t.refs[slot], kRefOverflow);
-                    }
-                    atomicAdd((unsigned long long *)&t.counts[slot], (unsigned long long)cnt);
-                    atomicAdd((unsigned long long *)&t.counters[C_ENTRIES], 1ull);
+            uint32_t tg = tag;
+            if (!claimed) {
+                tg = ld_agent(&t.tags[slot]);
+                if (tg == 0u) {
+                    tg = atomicCAS(&t.tags[slot], 0u, tag);
+                    claimed = tg == 0u;
+                }
+            }
+            if (claimed) {
+                uint64_t off = 0;
+                const int rc = arena_alloc(bt, t, nd, off);
+                if (rc == kAllocOk) {
+                    key.each(nd, [&](uint32_t d, uint32_t v) { st_agent(&t.arena[off + d], v); });
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    st_agent(&t.refs[slot], (off << 24) | kRefValid | (uint64_t)meta);
+                    atomicAdd(&bt.new_entries, 1u);
+                    found = slot;
+                    done = true;
+                } else if (rc == kAllocFull) {
+                    atomicOr((unsigned long long *)&t.counters[C_ERROR], 1ull);
+                    st_agent(&t.refs[slot], kRefOverflow);
                     done = true;
                 }
-                tg = old;
-            }
-            if (!done) {
-                if (tg == tag) {
-                    const uint64_t ref = ld_agent(&t.refs[slot]);
-                    if (ref == 0ull) {
-                        // claimed, key not yet published: look at the same slot again next trip
-                    } else if (ref == kRefOverflow) {
-                        done = true;
-                    } else {
-                        bool same = (uint32_t)(ref & 0x3FFFFull) == meta;
-                        if (same) {
-                            const uint64_t off = ref >> 24;
-                            uint32_t diff = 0;
-                            key.each(nd, [&](uint32_t d, uint32_t v) { diff |= ld_agent(&t.arena[off + d]) ^ v; });
-                            same = diff == 0u;
-                        }
-                        if (same) {
-                            atomicAdd((unsigned long long *)&t.counts[slot], (unsigned long long)cnt);
-                            done = true;
-                        } else {
-                            advance = true;
-                        }
-                    }
+            } else if (tg == tag) {
+                const uint64_t ref = ld_agent(&t.refs[slot]);
+                if (ref == 0ull) {
+                    // claimed by another lane, key not yet published: look at the same slot again next trip
+                } else if (ref == kRefOverflow) {
+                    done = true;
                 } else {
-                    advance = true;
-                }
-                if (advance) {
-                    slot = (slot + 1u) & t.slot_mask;
-                    if (++probes > t.slot_mask) {
-                        atomicOr((unsigned long long *)&t.counters[C_ERROR], 2ull);
-                        done = true;
+                    bool same = (uint32_t)(ref & 0x3FFFFull) == meta;
+                    if (same) {
+                        const uint64_t off = ref >> 24;
+                        uint32_t diff = 0;
+                        key.each(nd, [&](uint32_t d, uint32_t v) { diff |= ld_agent(&t.arena[off + d]) ^ v; });
+                        same = diff == 0u;
                     }
+                    if (same) { found = slot; done = true; }
+                    else advance = true;
+                }
+            } else {
+                advance = true;
+            }
+            if (advance) {
+                slot = (slot + 1u) & t.slot_mask;
+                if (++probes > t.slot_mask) {
+                    atomicOr((unsigned long long *)&t.counters[C_ERROR], 2ull);
+                    done = true;
                 }
             }
         }
     }
+    return found;
+}
+
+template <class K>
+__device__ __forceinline__ void table_add(const Table &t, BlockTable &bt, const K &key, uint32_t kind, uint32_t len, uint64_t cnt, bool active) {
+    const uint32_t slot = table_find_or_insert(t, bt, key, kind, len, active);
+    if (slot != kNoSlot) atomicAdd((unsigned long long *)&t.counts[slot], (unsigned long long)cnt);
+}
+
+// Workgroup-level count aggregation: a small LDS table keyed by slot index collects the +1s of a
+// whole workgroup (all its grid-stride iterations) and is flushed once at kernel end, so the Zipf
+// head of the variant distribution costs one global atomic per workgroup instead of one per read
+// (same-address global atomics serialise at ~10 ns each).  Slots that lose the LDS entry to another
+// slot fall through to a direct global atomic.
+constexpr int kAggSize = 1024;
+struct Agg {
+    uint32_t slot[kAggSize];
+    uint32_t cnt[kAggSize];
+};
+__device__ __forceinline__ void agg_init(Agg &a) {
+    for (int i = threadIdx.x; i < kAggSize; i += kBlock) { a.slot[i] = kNoSlot; a.cnt[i] = 0; }
+}
+__device__ __forceinline__ void agg_add(Agg &a, const Table &t, uint32_t slot) {
+    if (slot == kNoSlot) return;
+    const uint32_t i = (slot * 0x9E3779B1u) >> 22;                 // 10 bits
+    uint32_t cur = *(volatile uint32_t *)&a.slot[i];
+    if (cur == kNoSlot) { cur = atomicCAS(&a.slot[i], kNoSlot, slot); if (cur == kNoSlot) cur = slot; }
+    if (cur == slot) atomicAdd(&a.cnt[i], 1u);
+    else atomicAdd((unsigned long long *)&t.counts[slot], 1ull);
+}
+__device__ __forceinline__ void agg_flush(Agg &a, const Table &t) {
+    for (int i = threadIdx.x; i < kAggSize; i += kBlock)
+        if (a.slot[i] != kNoSlot && a.cnt[i]) atomicAdd((unsigned long long *)&t.counts[a.slot[i]], (unsigned long long)a.cnt[i]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -407,7 +501,13 @@ __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ 
     constexpr int MAXC = (16 * W) / 3;            // codons a row can hold
     constexpr int NDA = (MAXC + 3) / 4;           // peptide key dwords
     __shared__ uint8_t lut[64];
+    __shared__ Agg agg;
+    __shared__ BlockTable bt;
+    __shared__ uint32_t s_stat[2];
     if (threadIdx.x < 64) lut[threadIdx.x] = c_codon_le[threadIdx.x];
+    if (threadIdx.x < 2) s_stat[threadIdx.x] = 0;
+    agg_init(agg);
+    block_table_begin(bt, t);
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const uint64_t n_round = (n_reads + WAVE - 1) / WAVE * WAVE;
@@ -419,7 +519,7 @@ __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ 
             start = sp.x; end = sp.y;
             ok = start >= 0 && end >= 0 && start < end;             // lib.rs:288
         }
-        wave_count(&t.counters[C_ACCEPTED], ok);
+        wave_count_lds(&s_stat[0], ok);
         if (!__any(ok)) continue;
         uint32_t x[W + 2];
         if (ok) load_row<W>(rows, r, x);
@@ -450,8 +550,8 @@ __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ 
                 const uint32_t mask = rem >= 16 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (2 * rem)) - 1u));
                 key[w] = x[w] & mask;
             }
-            wave_count(&t.counters[C_COUNTED], ok);
-            table_add(t, RegKey<W>{key}, kKindPacked, L, 1ull, ok);
+            wave_count_lds(&s_stat[1], ok);
+            agg_add(agg, t, table_find_or_insert(t, bt, RegKey<W>{key}, kKindPacked, L, ok));
         } else {
             const bool tr = ok && (L % 3u) == 0u;                    // lib.rs:17-19
             const uint32_t nc = tr ? L / 3u : 0u;
@@ -475,9 +575,16 @@ __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ 
                 }
                 key[d] = kd;
             }
-            wave_count(&t.counters[C_COUNTED], tr);
-            table_add(t, RegKey<NDA>{key}, kKindBytes, nc, 1ull, tr);
+            wave_count_lds(&s_stat[1], tr);
+            agg_add(agg, t, table_find_or_insert(t, bt, RegKey<NDA>{key}, kKindBytes, nc, tr));
         }
+    }
+    __syncthreads();
+    agg_flush(agg, t);
+    block_table_end(bt, t);
+    if (threadIdx.x == 0) {
+        if (s_stat[0]) atomicAdd((unsigned long long *)&t.counters[C_ACCEPTED], (unsigned long long)s_stat[0]);
+        if (s_stat[1]) atomicAdd((unsigned long long *)&t.counters[C_COUNTED], (unsigned long long)s_stat[1]);
     }
 }
 
@@ -559,6 +666,11 @@ __global__ __launch_bounds__(kBlock) void k_generic(const uint8_t *__restrict__ 
                                                     uint64_t n_reads, GenericParams gp, int32_t *__restrict__ starts,
                                                     int32_t *__restrict__ ends, int32_t *__restrict__ ws, uint64_t st,
                                                     uint32_t ws_rows, Table t) {
+    __shared__ uint32_t s_stat[2];
+    __shared__ BlockTable bt;
+    if (threadIdx.x < 2) s_stat[threadIdx.x] = 0;
+    block_table_begin(bt, t);
+    __syncthreads();
     const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;   // < st by construction
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const uint64_t n_round = (n_reads + WAVE - 1) / WAVE * WAVE;
@@ -578,7 +690,7 @@ __global__ __launch_bounds__(kBlock) void k_generic(const uint8_t *__restrict__ 
         }
         if (!gp.count_mode) continue;
         const bool ok = valid && a >= 0 && b >= 0 && a < b;
-        wave_count(&t.counters[C_ACCEPTED], ok);
+        wave_count_lds(&s_stat[0], ok);
         const int64_t L = ok ? b - a : 0;
         const uint8_t *reg = s + (ok ? a : 0);
         uint32_t kind = kKindBytes, klen = 0;
@@ -624,8 +736,14 @@ __global__ __launch_bounds__(kBlock) void k_generic(const uint8_t *__restrict__ 
             }
         }
         (void)ws_rows;
-        wave_count(&t.counters[C_COUNTED], ins);
-        table_add(t, MemKey{stage, st}, kind, klen, 1ull, ins);
+        wave_count_lds(&s_stat[1], ins);
+        table_add(t, bt, MemKey{stage, st}, kind, klen, 1ull, ins);
+    }
+    __syncthreads();
+    block_table_end(bt, t);
+    if (threadIdx.x == 0) {
+        if (s_stat[0]) atomicAdd((unsigned long long *)&t.counters[C_ACCEPTED], (unsigned long long)s_stat[0]);
+        if (s_stat[1]) atomicAdd((unsigned long long *)&t.counters[C_COUNTED], (unsigned long long)s_stat[1]);
     }
 }
 
@@ -649,6 +767,9 @@ __global__ __launch_bounds__(kBlock) void k_export(Table t, uint64_t *__restrict
 
 __global__ __launch_bounds__(kBlock) void k_merge(Table t, const uint64_t *__restrict__ refs, const uint64_t *__restrict__ counts,
                                                   const uint32_t *__restrict__ arena, uint64_t n) {
+    __shared__ BlockTable bt;
+    block_table_begin(bt, t);
+    __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const uint64_t n_round = (n + WAVE - 1) / WAVE * WAVE;
     for (uint64_t e = (uint64_t)blockIdx.x * kBlock + threadIdx.x; e < n_round; e += stride) {
@@ -656,8 +777,10 @@ __global__ __launch_bounds__(kBlock) void k_merge(Table t, const uint64_t *__res
         uint64_t ref = 0, cnt = 0;
         if (valid) { ref = refs[e]; cnt = counts[e]; }
         const uint32_t len = (uint32_t)(ref & 0xFFFFull), kind = (uint32_t)((ref >> 16) & 3ull);
-        table_add(t, MemKey{arena + (ref >> 24), 1ull}, kind, len, cnt, valid);
+        table_add(t, bt, MemKey{arena + (ref >> 24), 1ull}, kind, len, cnt, valid);
     }
+    __syncthreads();
+    block_table_end(bt, t);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -669,6 +792,13 @@ static int grid_for(uint64_t n, int per_cu) {
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;
+}
+
+void scan_geometry(uint64_t n, uint32_t *grid, uint32_t *seg) {
+    const uint32_t g = (uint32_t)grid_for(n, 8);
+    const uint64_t per_block = (n + (uint64_t)g * kBlock - 1) / ((uint64_t)g * kBlock) * kBlock;
+    *grid = g;
+    *seg = (uint32_t)per_block;
 }
 
 static bool g_lut_ready[64];
@@ -690,29 +820,28 @@ static hipError_t ensure_lut() {
 hipError_t launch_scan(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n, const ScanParams &sp,
                        short2 *spans, BatchLists bl) {
     if (n == 0) return hipSuccess;
-    const int g = grid_for(n, 8);
+    uint32_t g, seg;
+    scan_geometry(n, &g, &seg);
+    if (bl.grid != g || bl.seg != seg) return hipErrorInvalidValue;
     switch (W) {
-    case 10: hipLaunchKernelGGL(k_scan<10>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, sp, spans, bl.listP, bl.listS, bl.cnt); break;
-    case 20: hipLaunchKernelGGL(k_scan<20>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, sp, spans, bl.listP, bl.listS, bl.cnt); break;
-    case 40: hipLaunchKernelGGL(k_scan<40>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, sp, spans, bl.listP, bl.listS, bl.cnt); break;
+    case 10: hipLaunchKernelGGL(k_scan<10>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, sp, spans, bl); break;
+    case 20: hipLaunchKernelGGL(k_scan<20>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, sp, spans, bl); break;
+    case 40: hipLaunchKernelGGL(k_scan<40>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, sp, spans, bl); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
 template <int M>
-static void launch_dp_m(hipStream_t s, int g, const uint32_t *rows, const uint16_t *lens, int W, const uint32_t *list,
-                        const uint32_t *count, const DpParams &dp, short2 *spans, uint32_t *listS, uint32_t *countS,
-                        uint64_t *counters) {
-    hipLaunchKernelGGL(k_dp<M>, dim3(g), dim3(kBlock), 0, s, rows, lens, W, list, count, dp, spans, listS, countS, counters);
+static void launch_dp_m(hipStream_t s, const uint32_t *rows, const uint16_t *lens, int W, const DpParams &dp, short2 *spans,
+                        BatchLists bl, uint64_t *counters) {
+    hipLaunchKernelGGL(k_dp<M>, dim3(bl.grid), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, counters);
 }
 
-hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n_bound, const uint32_t *list,
-                     const uint32_t *count, const DpParams &dp, short2 *spans, uint32_t *listS, uint32_t *countS,
-                     uint64_t *counters) {
-    if (n_bound == 0) return hipSuccess;
-    const int g = grid_for(n_bound, 8);
-#define VF_DP_CASE(M) case M: launch_dp_m<M>(s, g, rows, lens, W, list, count, dp, spans, listS, countS, counters); break;
+hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
+                     BatchLists bl, uint64_t *counters) {
+    if (bl.grid == 0) return hipSuccess;
+#define VF_DP_CASE(M) case M: launch_dp_m<M>(s, rows, lens, W, dp, spans, bl, counters); break;
     switch (dp.m) {
         VF_DP_CASE(1) VF_DP_CASE(2) VF_DP_CASE(3) VF_DP_CASE(4) VF_DP_CASE(5) VF_DP_CASE(6) VF_DP_CASE(7) VF_DP_CASE(8)
         VF_DP_CASE(9) VF_DP_CASE(10) VF_DP_CASE(11) VF_DP_CASE(12) VF_DP_CASE(13) VF_DP_CASE(14) VF_DP_CASE(15) VF_DP_CASE(16)
