@@ -175,27 +175,23 @@ class Engine:
         import torch
         import torch.distributed as dist
 
+        from .dist import allgather_blobs
+
         world = dist.get_world_size(group)
         rank = dist.get_rank(group)
         if world == 1:
             return 0.0
         dev = torch.device("cuda", self.device)
         mine = self.export_size()
-        sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-        sizes[rank] = mine
-        dist.all_reduce(sizes, group=group)
-        cap = int(sizes.max().item())
-        cap = (cap + 255) // 256 * 256
-        send = torch.zeros(cap, dtype=torch.uint8, device=dev)
-        self.export_to(send.data_ptr(), cap)
-        recv = torch.empty(world * cap, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(recv, send, group=group)
+        send = torch.zeros((mine + 255) // 256 * 256, dtype=torch.uint8, device=dev)
+        self.export_to(send.data_ptr(), send.numel())
+        parts = allgather_blobs(send, mine, group)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         if dst is None or rank == dst:
-            for r in range(world):
+            for r, (buf, nbytes) in enumerate(parts):
                 if r != rank:
-                    self.merge_from(recv.data_ptr() + r * cap, int(sizes[r].item()))
+                    self.merge_from(buf.data_ptr(), nbytes)
         return time.perf_counter() - t0
 
     # ---- stats ----------------------------------------------------------------------------------
