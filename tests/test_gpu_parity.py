@@ -171,6 +171,36 @@ def test_adapter_lengths(m):
     _check_spans(reads, ads, accept_prefix_alignment=0.8, accept_suffix_alignment=0.8)
 
 
+def test_filter_and_window_edge_cases():
+    """Myers pre-filter + windowed DP must equal the full DP: adapters overhanging either read end,
+    long insertions, several mutated copies far apart (hull wider than the window -> full-width DP),
+    windows touching column 0 and the last column"""
+    rng = np.random.default_rng(5)
+    P, S = AD20
+    mut = lambda a, i: a[:i] + ("A" if a[i] != "A" else "C") + a[i + 1:]
+    R = lambda k: synth.rand_seq(rng, k).decode()
+    reads = [mut(P, 3) + R(60) + mut(S, 10) + R(30),                 # window starts at column 0
+             P[3:] + R(70) + mut(S, 2) + R(20),                      # prefix overhangs the read start
+             R(5) + mut(P, 7) + R(60) + S[:17],                      # suffix overhangs the read end
+             R(9) + mut(P, 1) + R(40) + mut(P, 15) + R(30) + mut(S, 4) + R(4) + mut(S, 9),   # copies far apart
+             R(8) + P[:10] + "ACGTA" + P[10:] + R(50) + mut(S, 5) + R(20),                   # 5-base insertion
+             R(8) + P[:9] + P[11:] + R(50) + S[:12] + S[13:] + R(30),                        # deletions
+             mut(mut(P, 2), 12) + R(100) + mut(mut(S, 5), 17),       # two mismatches each, at both read ends
+             R(130) + mut(P, 5),                                     # prefix-like match at the very end
+             mut(S, 5) + R(130),                                     # suffix-like match at the very start
+             P[:15], S[5:], R(18), mut(P, 0), mut(S, 19)]
+    reads = [r.encode() for r in reads]
+    for kw in (dict(), dict(accept_prefix_alignment=0.6, accept_suffix_alignment=0.6),
+               dict(accept_prefix_alignment=0.9, accept_suffix_alignment=0.5),
+               dict(match_score=2, mismatch_score=-1, gap_open_penalty=3, gap_extend_penalty=1)):
+        _check_spans(reads, AD20, **kw)
+        _check_counts(reads, AD20, **kw)
+    # randomised: heavy indel noise and flanks on both sides, several thresholds
+    for seed, acc in ((201, 0.5), (202, 0.65), (203, 0.75), (204, 0.9)):
+        rd = synth.make_reads(seed, 3000, AD20, L=150, sub=0.08, indel=0.08, flank_max=40, vary_len=True)
+        _check_spans(rd, AD20, accept_prefix_alignment=acc, accept_suffix_alignment=acc)
+
+
 def test_small_batches_and_slot_reuse():
     reads = synth.make_reads(71, 5000, AD20, L=150, sub=0.02, indel=0.005, dirty=0.05)
     _check_counts(reads, AD20, batch_reads=257, queue_len=3)

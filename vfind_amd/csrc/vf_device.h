@@ -23,6 +23,7 @@ constexpr uint32_t kPrefMask = 7u << kPrefShift;
 constexpr uint32_t kLenMask = (1u << kPrefShift) - 1u;
 constexpr int kLenBias = 32;
 constexpr int kNegScore = -20000;
+constexpr uint32_t kMaxGrid = 2048;     // every kernel launches at most this many workgroups
 
 struct DpParams {
     uint64_t pat;        // adapter, 2 bits per base
@@ -36,6 +37,7 @@ struct DpParams {
     uint32_t pref6;      // 6 << kPrefShift
     uint32_t is_prefix;
     uint32_t independent; // 1 = test hook: run the suffix DP even when the prefix failed (lib.rs:278-286)
+    int32_t kerr;         // max unit edits of an acceptable alignment (pre-DP filter); <0 = none can pass
 };
 
 struct ScanParams {
@@ -75,7 +77,6 @@ enum Counter : int {        // uint64 counters[] in device memory
     C_NUM = 8
 };
 
-constexpr uint32_t kMaxGrid = 2048;     // every kernel launches at most this many workgroups
 constexpr uint32_t kChunkRows = 17;     // chunk-state rows: 16 batch streams + the main stream
 
 struct Table {
@@ -92,16 +93,22 @@ struct Table {
 
 // ---- launchers (vf_kernels.hip) ---------------------------------------------------------------
 struct BatchLists {        // per in-flight batch; lists are segmented per workgroup of k_scan
-    uint32_t *listP, *listS;   // grid*seg entries each
-    uint32_t *cntP, *cntS;     // grid entries each
-    uint32_t grid, seg;        // from scan_geometry(n)
+    uint32_t *listP, *listS;          // DP tasks per adapter (grid*seg entries each)
+    uint32_t *listW[3], *winW[3];     // filter output: windowed tasks by window-length class (+ a | b<<16)
+    uint32_t *listF;                  // filter output: tasks whose window exceeds the window kernel
+    uint32_t *cntP, *cntS, *cntW[3], *cntF;   // kMaxGrid entries each
+    uint32_t grid, seg;               // from scan_geometry(n)
 };
 
 void scan_geometry(uint64_t n, uint32_t *grid, uint32_t *seg);
 hipError_t launch_scan(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n,
                        const ScanParams &sp, short2 *spans, BatchLists bl);
+hipError_t launch_filter(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
+                         short2 *spans, BatchLists bl, uint64_t *counters);
+hipError_t launch_dp_window(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
+                            short2 *spans, BatchLists bl);
 hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
-                     short2 *spans, BatchLists bl, uint64_t *counters);
+                     short2 *spans, BatchLists bl, bool from_filter, uint64_t *counters);
 hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n,
                          const short2 *spans, uint32_t skip_translation, Table t);
 hipError_t launch_generic(hipStream_t s, const uint8_t *bytes, const uint64_t *offs, uint64_t n,

@@ -16,6 +16,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -132,7 +133,7 @@ template <typename T> struct PinBuf {
 
 struct Workspace {               // device scratch of one in-flight batch
     DevBuf<short2> spans;
-    DevBuf<uint32_t> listP, listS, cnt;
+    DevBuf<uint32_t> listP, listS, listW[3], winW[3], listF, cnt;
     int ensure(size_t n) {
         int rc;
         uint32_t g, seg;
@@ -140,9 +141,17 @@ struct Workspace {               // device scratch of one in-flight batch
         if ((rc = spans.ensure(n))) return rc;
         if ((rc = listP.ensure((size_t)g * seg))) return rc;
         if ((rc = listS.ensure((size_t)g * seg))) return rc;
-        return cnt.ensure(2 * 2048);
+        for (int q = 0; q < 3; ++q) {
+            if ((rc = listW[q].ensure((size_t)g * seg))) return rc;
+            if ((rc = winW[q].ensure((size_t)g * seg))) return rc;
+        }
+        if ((rc = listF.ensure((size_t)g * seg))) return rc;
+        return cnt.ensure(6 * kMaxGrid);
     }
-    void release() { spans.release(); listP.release(); listS.release(); cnt.release(); }
+    void release() {
+        spans.release(); listP.release(); listS.release(); listF.release(); cnt.release();
+        for (int q = 0; q < 3; ++q) { listW[q].release(); winW[q].release(); }
+    }
 };
 
 struct Slot {
@@ -177,6 +186,8 @@ struct vf_ctx {
     int64_t T_pre = 0, T_suf = 0;
     bool skip_translation = false;
     bool fast_ok = false;
+    uint32_t debug_flags = 0;    // VFIND_DEBUG_FLAGS: profiling aids for k_finish (0x100 no table, 0x200 no count)
+    bool filter_on = false;      // Myers pre-DP filter + windowed DP usable for these scores
     uint32_t n_threads = 3, queue_len = 2, batch_reads = 1u << 18;
     ScanParams sp{};
     DpParams dpP{}, dpS{};
@@ -240,6 +251,23 @@ static uint64_t pack_adapter(const std::string &s) {
     for (size_t i = 0; i < s.size(); ++i) v |= (uint64_t)(g_code[(unsigned char)s[i]] & 3u) << (2 * i);
     return v;
 }
+// Largest number of unit edits (mismatch, read base vs gap, adapter base vs gap, unaligned adapter end
+// base) an alignment with score >= T can contain.  Its loss against m matches is at most
+// L = match*m - T; a mismatch costs match-mismatch, an unaligned end base match, an adapter base in a
+// gap at least min(open,ext)+match, a read base in a gap `open` for the first of a gap and `ext` for
+// the rest.  Returns -1 when nothing can reach T, INT32_MAX when the scheme gives no bound.
+static int32_t max_unit_errors(int64_t T, size_t m, int32_t match, int32_t mismatch, int32_t gopen, int32_t gext) {
+    const int64_t L = (int64_t)match * (int64_t)m - T;
+    if (L < 0) return -1;
+    if (match < 1 || match - mismatch < 1 || gext < 1 || gopen < 0) return INT32_MAX;
+    const int64_t c_other = std::min<int64_t>(std::min<int64_t>(match, match - mismatch), std::min(gopen, gext) + (int64_t)match);
+    int64_t best = L / c_other;
+    for (int64_t g = 1; g * gopen <= L && g <= 4096; ++g)            // g read-side gaps, total length len
+        for (int64_t len = g; g * gopen + (len - g) * gext <= L; ++len)
+            best = std::max(best, len + (L - g * gopen - (len - g) * gext) / c_other);
+    return best > 1000000 ? INT32_MAX : (int32_t)best;
+}
+
 static void fill_dp(DpParams &d, const std::string &ad, int64_t T, const vf_ctx &c, bool is_prefix) {
     d.pat = pack_adapter(ad);
     d.m = (uint32_t)ad.size();
@@ -256,6 +284,8 @@ static void fill_dp(DpParams &d, const std::string &ad, int64_t T, const vf_ctx 
     d.pref_clear = ~kPrefMask;
     d.pref6 = 6u << kPrefShift;
     d.is_prefix = is_prefix ? 1u : 0u;
+    d.independent = 0;
+    d.kerr = max_unit_errors(T, ad.size(), c.match, c.mismatch, c.gopen, c.gext);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -293,6 +323,7 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     c->queue_len = std::min<uint32_t>(std::max<uint32_t>(p->queue_len, 1), 16);
     c->batch_reads = p->batch_reads ? p->batch_reads : (1u << 18);
     c->dev = p->device;
+    if (const char *dbg = getenv("VFIND_DEBUG_FLAGS")) c->debug_flags = (uint32_t)strtoul(dbg, nullptr, 0) & 0xFF00u;
 
     // can the 2-bit fast path hold these adapters and scores?  (else every read goes byte-wise)
     auto small = [](int32_t v) { return v >= -127 && v <= 127; };
@@ -326,6 +357,9 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
         c->sp.align_pre = c->skip_pre ? 0 : 1; c->sp.align_suf = c->skip_suf ? 0 : 1;
         fill_dp(c->dpP, c->pre, c->T_pre, *c, true);
         fill_dp(c->dpS, c->suf, c->T_suf, *c, false);
+        // window = m + kerr columns (+ spread of the end columns) must fit the 64 the kernel holds
+        auto usable = [](const DpParams &d) { return d.kerr < 0 || (int64_t)d.m + d.kerr <= 48; };
+        c->filter_on = usable(c->dpP) && usable(c->dpS);
     }
 
     // count table
@@ -416,18 +450,33 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
                       const uint16_t *d_lens, uint64_t n, short2 *d_spans, bool count) {
     if (n == 0) return VF_OK;
     if (n > 0xFFFFFFF0ull) return fail(VF_EINVAL, "batch too large (max 2^32-16 reads per submission)");
-    BatchLists bl{ws.listP.p, ws.listS.p, ws.cnt.p, ws.cnt.p + 2048, 0, 0};
+    BatchLists bl{};
+    bl.listP = ws.listP.p; bl.listS = ws.listS.p; bl.listF = ws.listF.p;
+    bl.cntP = ws.cnt.p; bl.cntS = ws.cnt.p + kMaxGrid; bl.cntF = ws.cnt.p + 2 * kMaxGrid;
+    for (int q = 0; q < 3; ++q) { bl.listW[q] = ws.listW[q].p; bl.winW[q] = ws.winW[q].p; bl.cntW[q] = ws.cnt.p + (3 + q) * kMaxGrid; }
     scan_geometry(n, &bl.grid, &bl.seg);
     // counting mode skips the suffix alignment of a read whose prefix failed (same table, less work);
     // the spans test hook keeps the two searches independent, as find_adapter_match is called (lib.rs:278-286)
     ScanParams sp = c->sp; DpParams dpP = c->dpP, dpS = c->dpS;
     sp.independent = dpP.independent = dpS.independent = count ? 0u : 1u;
     { Timed t(c, st, K_SCAN); HIP_TRY(launch_scan(st, W, d_rows, d_lens, n, sp, d_spans, bl)); }
-    if (!c->skip_pre) { Timed t(c, st, K_DPP); HIP_TRY(launch_dp(st, W, d_rows, d_lens, dpP, d_spans, bl, c->tab.counters)); }
-    if (!c->skip_suf) { Timed t(c, st, K_DPS); HIP_TRY(launch_dp(st, W, d_rows, d_lens, dpS, d_spans, bl, c->tab.counters)); }
+    // per adapter: Myers filter -> windowed DP (-> full-width DP for the rare over-long window), or the
+    // full-width DP alone when the scoring scheme gives the filter no usable edit bound
+    for (int role = 0; role < 2; ++role) {
+        if (role == 0 ? c->skip_pre : c->skip_suf) continue;
+        const DpParams &dp = role == 0 ? dpP : dpS;
+        Timed t(c, st, role == 0 ? K_DPP : K_DPS);
+        if (c->filter_on) {
+            HIP_TRY(launch_filter(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters));
+            HIP_TRY(launch_dp_window(st, W, d_rows, d_lens, dp, d_spans, bl));
+            HIP_TRY(launch_dp(st, W, d_rows, d_lens, dp, d_spans, bl, true, c->tab.counters));
+        } else {
+            HIP_TRY(launch_dp(st, W, d_rows, d_lens, dp, d_spans, bl, false, c->tab.counters));
+        }
+    }
     Table tab = c->tab;
     tab.chunk_row = chunk_row;
-    if (count) { Timed t(c, st, K_FIN); HIP_TRY(launch_finish(st, W, d_rows, d_lens, n, d_spans, c->skip_translation ? 1 : 0, tab)); }
+    if (count) { Timed t(c, st, K_FIN); HIP_TRY(launch_finish(st, W, d_rows, d_lens, n, d_spans, (c->skip_translation ? 1u : 0u) | c->debug_flags, tab)); }
     return VF_OK;
 }
 

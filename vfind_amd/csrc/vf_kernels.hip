@@ -246,47 +246,305 @@ __device__ __forceinline__ void dp_align(const uint32_t *__restrict__ row, int n
     len = blen;
 }
 
-// block b consumes segment b of its role's list (written by block b of k_scan / of the prefix pass)
+// outcome of one alignment task -> spans (+ suffix task for an accepted prefix)
+__device__ __forceinline__ bool dp_commit(bool valid, uint32_t r, int n, bool ok, int len, const DpParams &dp,
+                                          short2 *__restrict__ spans) {
+    bool pushS = false;
+    if (valid) {
+        short2 sp = spans[r];
+        if (dp.is_prefix) {
+            sp.x = ok ? (short)len : kNone;
+            pushS = !dp.independent && ok && sp.y == kPending;
+            if (!dp.independent && !ok && sp.y == kPending) sp.y = kNone;
+        } else {
+            sp.y = (ok && len <= n) ? (short)(n - len) : kNone;
+        }
+        spans[r] = sp;
+    }
+    return pushS;
+}
+
+// ---- dense consumption of a segmented list ---------------------------------------------------------
+// Producers write segment b at list[b*seg ..) with cnt[b] entries.  A consumer turns the segments
+// into one flat index space with an exclusive prefix sum of cnt[] kept in LDS and finds a task's
+// segment by binary search, so its waves are full however unevenly the segments are filled (a
+// per-segment consumer ran mostly-empty waves whenever segments held only a few tasks).
+struct FlatList {
+    uint32_t pre[kMaxGrid + 1];
+    uint32_t scan[kBlock];
+};
+__device__ __forceinline__ void flat_build(FlatList &f, const uint32_t *__restrict__ cnt, uint32_t G) {
+    constexpr int PER = kMaxGrid / kBlock;      // 8
+    uint32_t loc[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t idx = PER * threadIdx.x + k;
+        const uint32_t v = idx < G ? cnt[idx] : 0u;
+        loc[k] = sum;
+        sum += v;
+    }
+    f.scan[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < kBlock; off <<= 1) {
+        const uint32_t v = (int)threadIdx.x >= off ? f.scan[threadIdx.x - off] : 0u;
+        __syncthreads();
+        f.scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const uint32_t excl = f.scan[threadIdx.x] - sum;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) f.pre[PER * threadIdx.x + k] = excl + loc[k];
+    if (threadIdx.x == kBlock - 1) f.pre[kMaxGrid] = f.scan[kBlock - 1];
+    __syncthreads();
+}
+// segment holding flat task t (t < total): largest s with pre[s] <= t and pre[s+1] > t
+__device__ __forceinline__ uint32_t flat_segment(const FlatList &f, uint32_t t) {
+    uint32_t lo = 0, hi = kMaxGrid;             // pre[lo] <= t < pre[hi]
+#pragma unroll
+    for (int it = 0; it < 11; ++it) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (f.pre[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// append read r to the suffix list segment of its own scan workgroup (capacity: a read enters listS
+// at most once, by k_scan or by the prefix pass); lanes of a wave mostly share the segment
+__device__ __forceinline__ void push_suffix(const BatchLists &bl, uint32_t seg, uint32_t r, bool want) {
+    uint64_t pending = __ballot(want);
+    while (pending) {
+        const uint32_t lead = __ffsll((unsigned long long)pending) - 1;
+        const uint32_t sseg = __shfl(seg, lead);
+        const uint64_t grp = __ballot(want && seg == sseg) & pending;
+        uint32_t base = 0;
+        if (lane_id() == lead) base = atomicAdd(&bl.cntS[sseg], (uint32_t)__popcll(grp));
+        base = __shfl(base, lead);
+        if (want && seg == sseg && ((grp >> lane_id()) & 1ull))
+            bl.listS[(uint64_t)sseg * bl.seg + base + __popcll(grp & ((1ull << lane_id()) - 1ull))] = r;
+        pending &= ~grp;
+    }
+}
+
+// Full-width DP over the tasks of the segmented list (list, cnt)
 template <int M>
 __global__ __launch_bounds__(kBlock) void k_dp(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
                                                DpParams dp, short2 *__restrict__ spans, BatchLists bl,
-                                               uint64_t *__restrict__ counters) {
-    __shared__ uint32_t s_cntS;
-    const uint32_t *list = dp.is_prefix ? bl.listP : bl.listS;
-    const uint32_t ntask = (dp.is_prefix ? bl.cntP : bl.cntS)[blockIdx.x];
-    if (threadIdx.x == 0) s_cntS = bl.cntS[blockIdx.x];
-    __syncthreads();
-    const uint32_t n_round = (ntask + WAVE - 1) / WAVE * WAVE;
-    const uint64_t seg0 = (uint64_t)blockIdx.x * bl.seg;
-    for (uint32_t t = threadIdx.x; t < n_round; t += kBlock) {
-        const bool valid = t < ntask;
-        uint32_t r = 0;
+                                               const uint32_t *__restrict__ list, const uint32_t *__restrict__ cnt,
+                                               uint32_t count_stat, uint64_t *__restrict__ counters) {
+    __shared__ FlatList fl;
+    flat_build(fl, cnt, bl.grid);
+    const uint32_t total = fl.pre[kMaxGrid];
+    const uint32_t n_round = (total + WAVE - 1) / WAVE * WAVE;
+    for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < n_round; t += gridDim.x * kBlock) {
+        const bool valid = t < total;
+        uint32_t r = 0, seg = 0;
         int n = 0;
-        if (valid) { r = list[seg0 + t]; n = lens[r]; }
+        if (valid) {
+            seg = flat_segment(fl, t);
+            r = list[(uint64_t)seg * bl.seg + (t - fl.pre[seg])];
+            n = lens[r];
+        }
         int score, len;
         dp_align<M>(rows + (uint64_t)r * W, n, dp, score, len);
-        bool pushS = false;
-        if (valid) {
-            short2 sp = spans[r];
-            const bool ok = score >= dp.T;
-            if (dp.is_prefix) {
-                sp.x = ok ? (short)len : kNone;
-                pushS = !dp.independent && ok && sp.y == kPending;
-                if (!dp.independent && !ok && sp.y == kPending) sp.y = kNone;
-            } else {
-                sp.y = (ok && len <= n) ? (short)(n - len) : kNone;
+        const bool pushS = dp_commit(valid, r, n, score >= dp.T, len, dp, spans);
+        if (dp.is_prefix) push_suffix(bl, seg, r, pushS);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && count_stat && total)
+        atomicAdd((unsigned long long *)&counters[dp.is_prefix ? C_DP_PREFIX : C_DP_SUFFIX], (unsigned long long)total);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_filter: Myers bit-vector approximate matching as an exact pre-DP filter.
+//
+// Any alignment the reference would accept (score >= T) loses at most match*m - T against a perfect
+// match, hence has at most dp.kerr unit edits (host: max_unit_errors), hence its end column j has
+// unit edit distance D[m][j] <= kerr (free start in the read, D[i][0] = i; an adapter overhanging
+// the read end is covered because D[m][n] <= D[i][n] + (m-i)), and it spans fewer than m + kerr
+// columns.  So every cell on an accepting path lies in columns (jmin - m - kerr, jmax], where
+// jmin/jmax are the first/last columns with D[m][j] <= kerr.  Cells off every accepting path can be
+// lowered to -inf without changing any cell on one (an optimal predecessor of such a cell is itself
+// on an accepting path), so the DP restricted to that window returns the same score, end cell and
+// length whenever the full DP would accept, and rejects whenever it would reject.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int n, const DpParams &dp, int &jmin, int &jmax) {
+    uint32_t Pv = 0xFFFFFFFFu, Mv = 0u;
+    int sc = (int)dp.m;
+    const uint32_t hs = dp.m - 1u;
+    jmin = 0x7FFFFFFF;
+    jmax = 0;
+    const int nwords = (n + 15) >> 4;
+    uint32_t word_next = nwords > 0 ? row[0] : 0u;
+    for (int w = 0; w < nwords; ++w) {
+        uint32_t word = word_next;
+        if (w + 1 < nwords) word_next = row[w + 1];
+        const int kmax = min(16, n - 16 * w);
+        for (int k = 0; k < kmax; ++k) {
+            const uint32_t c = word & 3u;
+            word >>= 2;
+            const uint32_t eq_lo = (c & 1u) ? dp.eq[1] : dp.eq[0];
+            const uint32_t eq_hi = (c & 1u) ? dp.eq[3] : dp.eq[2];
+            const uint32_t Eq = (c & 2u) ? eq_hi : eq_lo;
+            const uint32_t Xv = Eq | Mv;
+            const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            uint32_t Ph = Mv | ~(Xh | Pv);
+            uint32_t Mh = Pv & Xh;
+            sc += (int)((Ph >> hs) & 1u) - (int)((Mh >> hs) & 1u);
+            Ph <<= 1;
+            Mh <<= 1;
+            Pv = Mh | ~(Xv | Ph);
+            Mv = Ph & Xv;
+            if (sc <= dp.kerr) {
+                const int j = 16 * w + k + 1;
+                jmin = min(jmin, j);
+                jmax = j;
             }
-            spans[r] = sp;
-        }
-        if (dp.is_prefix) {
-            const uint32_t is = wave_append(&s_cntS, pushS);
-            if (pushS) bl.listS[seg0 + is] = r;
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (dp.is_prefix) bl.cntS[blockIdx.x] = s_cntS;
-        if (ntask) atomicAdd((unsigned long long *)&counters[dp.is_prefix ? C_DP_PREFIX : C_DP_SUFFIX], (unsigned long long)ntask);
+}
+
+constexpr int kMaxWindow = 64;   // columns the windowed DP holds in registers (5 dwords incl. phase)
+// window-length classes: tasks of similar trip count share waves (a wave runs its longest window)
+__device__ __forceinline__ int window_class(int wl, int base) {
+    if (wl <= base + 8) return 0;
+    if (wl <= base + 20) return 1;
+    return wl <= kMaxWindow ? 2 : 3;           // 3 = wider than the window kernel holds -> full-width DP
+}
+
+__global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
+                                                   DpParams dp, short2 *__restrict__ spans, BatchLists bl,
+                                                   uint64_t *__restrict__ counters) {
+    __shared__ uint32_t s_c[4];
+    const uint32_t *list = dp.is_prefix ? bl.listP : bl.listS;
+    const uint32_t *cnt = dp.is_prefix ? bl.cntP : bl.cntS;
+    uint32_t stat = 0;
+    for (uint32_t b = blockIdx.x; b < bl.grid; b += gridDim.x) {
+        const uint32_t ntask = cnt[b];
+        if (threadIdx.x < 4) s_c[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t n_round = (ntask + WAVE - 1) / WAVE * WAVE;
+        const uint64_t seg0 = (uint64_t)b * bl.seg;
+        for (uint32_t t = threadIdx.x; t < n_round; t += kBlock) {
+            const bool valid = t < ntask;
+            uint32_t r = 0;
+            int n = 0;
+            if (valid) { r = list[seg0 + t]; n = lens[r]; }
+            int jmin, jmax;
+            myers_scan(rows + (uint64_t)r * W, n, dp, jmin, jmax);
+            const bool any = valid && jmax > 0;
+            if (valid && !any) (void)dp_commit(true, r, n, false, 0, dp, spans);
+            const int a = max(0, jmin - (int)dp.m - dp.kerr);
+            const int cls = window_class(jmax - a, (int)dp.m + dp.kerr);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const bool mine = any && cls == q;
+                const uint32_t iw = wave_append(&s_c[q], mine);
+                if (mine) { bl.listW[q][seg0 + iw] = r; bl.winW[q][seg0 + iw] = (uint32_t)a | ((uint32_t)jmax << 16); }
+            }
+            const bool toF = any && cls == 3;
+            const uint32_t jf = wave_append(&s_c[3], toF);
+            if (toF) bl.listF[seg0 + jf] = r;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) bl.cntW[threadIdx.x][b] = s_c[threadIdx.x];
+        if (threadIdx.x == 3) bl.cntF[b] = s_c[3];
+        stat += ntask;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && stat)
+        atomicAdd((unsigned long long *)&counters[dp.is_prefix ? C_DP_PREFIX : C_DP_SUFFIX], (unsigned long long)stat);
+}
+
+// the same DP as dp_align over read columns (a, b] only; column a is the boundary: the true first
+// column when a == 0, otherwise -inf (every cell left of the window is off all accepting paths)
+template <int M>
+__device__ __forceinline__ void dp_window(const uint32_t *__restrict__ row, int W, int n, int a, int b, const DpParams &dp,
+                                          int &score, int &len) {
+    int32_t Hc[M], Ec[M];
+    const int32_t negv = (int32_t)((uint32_t)kNegScore << kScoreShift);
+    const int32_t negh = negv | (int32_t)(6u << kPrefShift);
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        const int32_t h0 = (int32_t)(((uint32_t)(-dp.mismatch * (i + 1)) << kScoreShift) | (6u << kPrefShift) | (uint32_t)(kLenBias - (i + 1)));
+        Hc[i] = a == 0 ? h0 : negh;
+        Ec[i] = negv;
+    }
+    const int32_t v0 = (int32_t)((6u << kPrefShift) | (uint32_t)kLenBias);
+    const uint32_t clr = dp.pref_clear;
+    int32_t pref6 = (int32_t)dp.pref6;
+    asm volatile("" : "+v"(pref6));
+    // 5 dwords hold the window (phase <= 15 bases + 64 columns = 79 <= 80 bases)
+    const int wi = a >> 4;
+    uint32_t q0 = wi + 0 < W ? row[wi + 0] : 0u;
+    uint32_t q1 = wi + 1 < W ? row[wi + 1] : 0u;
+    uint32_t q2 = wi + 2 < W ? row[wi + 2] : 0u;
+    uint32_t q3 = wi + 3 < W ? row[wi + 3] : 0u;
+    uint32_t q4 = wi + 4 < W ? row[wi + 4] : 0u;
+    const uint32_t ph = 2u * (uint32_t)(a & 15);
+    q0 = funnel(q1, q0, ph); q1 = funnel(q2, q1, ph); q2 = funnel(q3, q2, ph); q3 = funnel(q4, q3, ph); q4 >>= ph;
+    int32_t best_s = INT32_MIN, best_v = 0;
+    const int wlen = b - a;
+    for (int t = 0; t < wlen; ++t) {
+        const uint32_t c = q0 & 3u;
+        q0 = funnel(q1, q0, 2); q1 = funnel(q2, q1, 2); q2 = funnel(q3, q2, 2); q3 = funnel(q4, q3, 2); q4 >>= 2;
+        const uint32_t eq_lo = (c & 1u) ? dp.eq[1] : dp.eq[0];
+        const uint32_t eq_hi = (c & 1u) ? dp.eq[3] : dp.eq[2];
+        const uint32_t eq = (c & 2u) ? eq_hi : eq_lo;
+        int32_t hdiag = v0, hup = v0, f1 = negv;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            const int32_t hc = Hc[i], ec = Ec[i];
+            const int32_t e = max(hc + dp.e_open_k, ec + dp.e_ext_k) & (int32_t)~kPrefMask;
+            const int32_t f = max(hup + dp.f_open_k, f1 + dp.f_ext_k) | (int32_t)(1u << kPrefShift);
+            const int32_t d = v_mad24(__builtin_amdgcn_ubfe(eq, i, 1), dp.delta, hdiag);
+            const int32_t h = v_and_or(max(max(d, f), e), clr, pref6);
+            hdiag = hc;
+            Hc[i] = h;
+            Ec[i] = e;
+            hup = h;
+            f1 = f;
+        }
+        const int32_t s = hup >> kScoreShift;
+        if (s > best_s) { best_s = s; best_v = hup; }
+    }
+    if (wlen <= 0) { score = INT32_MIN / 2; len = 0; return; }
+    int bscore = best_s + dp.mismatch * M;
+    int blen = (int)((uint32_t)best_v & kLenMask) + M - kLenBias;
+    if (b == n) {
+#pragma unroll
+        for (int i = 0; i < M - 1; ++i) {
+            const int si = (Hc[i] >> kScoreShift) + dp.mismatch * (i + 1);
+            if (si > bscore) { bscore = si; blen = (int)((uint32_t)Hc[i] & kLenMask) + (i + 1) - kLenBias; }
+        }
+    }
+    score = bscore;
+    len = blen;
+}
+
+template <int M>
+__global__ __launch_bounds__(kBlock) void k_dpw(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
+                                                DpParams dp, short2 *__restrict__ spans, BatchLists bl, int cls) {
+    __shared__ FlatList fl;
+    const uint32_t *list = bl.listW[cls], *win = bl.winW[cls];
+    flat_build(fl, bl.cntW[cls], bl.grid);
+    const uint32_t total = fl.pre[kMaxGrid];
+    const uint32_t n_round = (total + WAVE - 1) / WAVE * WAVE;
+    for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < n_round; t += gridDim.x * kBlock) {
+        const bool valid = t < total;
+        uint32_t r = 0, seg = 0;
+        int n = 0, wa = 0, wb = 0;
+        if (valid) {
+            seg = flat_segment(fl, t);
+            const uint64_t at = (uint64_t)seg * bl.seg + (t - fl.pre[seg]);
+            r = list[at];
+            n = lens[r];
+            const uint32_t w = win[at];
+            wa = (int)(w & 0xFFFFu);
+            wb = (int)(w >> 16);
+        }
+        int score, len;
+        dp_window<M>(rows + (uint64_t)r * W, W, n, wa, wb, dp, score, len);
+        const bool pushS = dp_commit(valid, r, n, score >= dp.T, len, dp, spans);
+        if (dp.is_prefix) push_suffix(bl, seg, r, pushS);
     }
 }
 
@@ -541,7 +799,7 @@ __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ 
 #pragma unroll
         for (int w = 0; w < W; ++w) x[w] = funnel(x[w + 1], x[w], bs);
         const uint32_t L = ok ? (uint32_t)(end - start) : 0u;
-        if (skip_translation) {
+        if (skip_translation & 1u) {
             // key = the region itself, 2 bits per base (expanded to letters by the host)
             uint32_t key[W];
 #pragma unroll
@@ -576,7 +834,16 @@ __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ 
                 key[d] = kd;
             }
             wave_count_lds(&s_stat[1], tr);
-            agg_add(agg, t, table_find_or_insert(t, bt, RegKey<NDA>{key}, kKindBytes, nc, tr));
+            if (skip_translation & 0x100u) {            // profiling aid: hash only, no table traffic
+                uint32_t acc = 0;
+#pragma unroll
+                for (int d = 0; d < NDA; ++d) acc ^= key[d];
+                if (acc == 0x12345678u && tr) atomicAdd(&s_stat[0], 1u);
+            } else {
+                const uint32_t slot = table_find_or_insert(t, bt, RegKey<NDA>{key}, kKindBytes, nc, tr);
+                if (!(skip_translation & 0x200u)) agg_add(agg, t, slot);
+                else if (slot == 0x7FFFFFFFu) atomicAdd(&s_stat[0], 1u);
+            }
         }
     }
     __syncthreads();
@@ -833,15 +1100,19 @@ hipError_t launch_scan(hipStream_t s, int W, const uint32_t *rows, const uint16_
 }
 
 template <int M>
-static void launch_dp_m(hipStream_t s, const uint32_t *rows, const uint16_t *lens, int W, const DpParams &dp, short2 *spans,
-                        BatchLists bl, uint64_t *counters) {
-    hipLaunchKernelGGL(k_dp<M>, dim3(bl.grid), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, counters);
+static void launch_dp_m(hipStream_t s, int which, int g, const uint32_t *rows, const uint16_t *lens, int W, const DpParams &dp,
+                        short2 *spans, BatchLists bl, const uint32_t *list, const uint32_t *cnt, uint32_t count_stat,
+                        uint64_t *counters) {
+    if (which == 0) hipLaunchKernelGGL(k_dp<M>, dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, list, cnt, count_stat, counters);
+    else hipLaunchKernelGGL(k_dpw<M>, dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, which - 1);
 }
 
-hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
-                     BatchLists bl, uint64_t *counters) {
+static hipError_t launch_dp_any(hipStream_t s, int which, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
+                                short2 *spans, BatchLists bl, const uint32_t *list, const uint32_t *cnt, uint32_t count_stat,
+                                uint64_t *counters) {
     if (bl.grid == 0) return hipSuccess;
-#define VF_DP_CASE(M) case M: launch_dp_m<M>(s, rows, lens, W, dp, spans, bl, counters); break;
+    const int g = (int)(bl.grid < 1024u ? bl.grid : 1024u);
+#define VF_DP_CASE(M) case M: launch_dp_m<M>(s, which, g, rows, lens, W, dp, spans, bl, list, cnt, count_stat, counters); break;
     switch (dp.m) {
         VF_DP_CASE(1) VF_DP_CASE(2) VF_DP_CASE(3) VF_DP_CASE(4) VF_DP_CASE(5) VF_DP_CASE(6) VF_DP_CASE(7) VF_DP_CASE(8)
         VF_DP_CASE(9) VF_DP_CASE(10) VF_DP_CASE(11) VF_DP_CASE(12) VF_DP_CASE(13) VF_DP_CASE(14) VF_DP_CASE(15) VF_DP_CASE(16)
@@ -850,6 +1121,31 @@ hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t 
     default: return hipErrorInvalidValue;
     }
 #undef VF_DP_CASE
+    return hipGetLastError();
+}
+
+// full-width DP over the role's own list (no filter) or over the filter's overflow list
+hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
+                     BatchLists bl, bool from_filter, uint64_t *counters) {
+    const uint32_t *list = from_filter ? bl.listF : (dp.is_prefix ? bl.listP : bl.listS);
+    const uint32_t *cnt = from_filter ? bl.cntF : (dp.is_prefix ? bl.cntP : bl.cntS);
+    return launch_dp_any(s, 0, W, rows, lens, dp, spans, bl, list, cnt, from_filter ? 0u : 1u, counters);
+}
+
+hipError_t launch_dp_window(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
+                            BatchLists bl) {
+    for (int cls = 0; cls < 3; ++cls) {
+        hipError_t e = launch_dp_any(s, 1 + cls, W, rows, lens, dp, spans, bl, nullptr, nullptr, 0u, nullptr);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_filter(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
+                         BatchLists bl, uint64_t *counters) {
+    if (bl.grid == 0) return hipSuccess;
+    const int g = (int)(bl.grid < 1024u ? bl.grid : 1024u);
+    hipLaunchKernelGGL(k_filter, dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, counters);
     return hipGetLastError();
 }
 
