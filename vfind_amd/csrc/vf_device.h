@@ -15,7 +15,7 @@ constexpr int16_t kPending = -2;      // span coordinate: waits for the DP kerne
 
 // ---- packed DP cell value (see DESIGN.md "DP cell encoding") ---------------------------------
 //   bits 31..13  score, biased by -mismatch*row      (signed)
-//   bits 12..10  tie preference (diag 6 > F 5/4 > E 1/0), cleared/normalised after every max
+//   bits 12..10  tie preference (diag 4 > F 3/2 > E 1/0), cleared/normalised after every max
 //   bits  9..0   alignment length, biased by 32-row
 constexpr int kScoreShift = 13;
 constexpr int kPrefShift = 10;
@@ -33,8 +33,6 @@ struct DpParams {
     int32_t mismatch;    // for un-biasing
     int32_t e_open_k, e_ext_k, f_open_k, f_ext_k;  // packed additive constants
     uint32_t delta;      // (match - mismatch) << kScoreShift
-    uint32_t pref_clear; // ~kPrefMask (kept opaque so it stays in an SGPR for v_and_or_b32)
-    uint32_t pref6;      // 6 << kPrefShift
     uint32_t is_prefix;
     uint32_t independent; // 1 = test hook: run the suffix DP even when the prefix failed (lib.rs:278-286)
     int32_t kerr;         // max unit edits of an acceptable alignment (pre-DP filter); <0 = none can pass

@@ -276,13 +276,11 @@ static void fill_dp(DpParams &d, const std::string &ad, int64_t T, const vf_ctx 
     d.T = (int32_t)std::max<int64_t>(std::min<int64_t>(T, INT32_MAX), INT32_MIN + 1);
     d.mismatch = c.mismatch;
     const int32_t S = 1 << kScoreShift, P = 1 << kPrefShift;
-    d.e_open_k = -c.gopen * S - 6 * P + 1;                    // H(pref 6) -> pref 0, len+1
+    d.e_open_k = -c.gopen * S + 1;                             // H(pref 0) -> pref 0, len+1
     d.e_ext_k = -c.gext * S + 1 * P + 1;                      // E(pref 0) -> pref 1, len+1
-    d.f_open_k = -(c.gopen + c.mismatch) * S - 2 * P;          // H(pref 6) -> pref 4, row bias
-    d.f_ext_k = -(c.gext + c.mismatch) * S;                    // F(pref 5) stays 5, row bias
+    d.f_open_k = -(c.gopen + c.mismatch) * S + 2 * P;          // H(pref 0) -> pref 2, row bias
+    d.f_ext_k = -(c.gext + c.mismatch) * S;                    // F(pref 3) stays 3, row bias
     d.delta = (uint32_t)(c.match - c.mismatch) << kScoreShift;
-    d.pref_clear = ~kPrefMask;
-    d.pref6 = 6u << kPrefShift;
     d.is_prefix = is_prefix ? 1u : 0u;
     d.independent = 0;
     d.kerr = max_unit_errors(T, ad.size(), c.match, c.mismatch, c.gopen, c.gext);

@@ -171,79 +171,132 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ ro
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_dp: semi-global affine-gap DP with the length statistic, one task (read, adapter) per lane.
-// Adapter rows live in VGPRs (Hc/Ec, packed score|pref|len), the read streams in 16 bases a dword.
-// 12 VALU ops per cell; see DESIGN.md for the encoding and the tie-policy argument.
+// Semi-global affine-gap DP with the length statistic, one task (read, adapter) per lane.
+// Adapter rows live in VGPRs as packed cells  score<<13 | pref<<10 | len  (vf_device.h); the
+// substitution term comes from a 4 x M profile in LDS (one ds_read_b128 per 4 rows, bank-conflict
+// free with a 36-dword row stride), so the LDS pipe, not the VALU, pays for it.
+//
+// gfx950 issues add/sub/shift/and/or/xor at full rate but min/max, v_max3, v_bfe, v_mad_u32_u24,
+// v_and_or, v_alignbit, v_cndmask, v_cmp at HALF rate (scripts/ubench/valu_rate*.hip), so the cell is
+// built from full-rate ops except the three unavoidable maxima:
+//   E: add add max and | F: add add max or | diag: add (+LDS) | H: max3 and   = 14 issue units
+// Two columns are unrolled with ping-pong register sets so no cell value is ever copied.
+//
+// Tie policy P through the 3-bit preference field: candidates enter each max with distinct
+// preferences (E: open 0 < extend 1;  F: open 2 < extend 3;  H: diag 4 > F 3 > E 0), the integer max
+// therefore picks exactly the policy's winner and carries its length; the field is cleared / set to
+// its standing value right after (H, E -> 0; F -> 3).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int32_t v_and_or(int32_t x, uint32_t mask_s, int32_t or_v) {
-    int32_t r;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(mask_s), "v"(or_v));
-    return r;
-}
-__device__ __forceinline__ int32_t v_mad24(uint32_t bit, uint32_t delta_s, int32_t add_v) {
-    int32_t r;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(bit), "s"(delta_s), "v"(add_v));
-    return r;
+constexpr int kProfStride = 36;                      // dwords per base in the LDS profile
+constexpr int32_t kClr = (int32_t)~kPrefMask;
+constexpr int32_t kV0 = kLenBias;                    // H[0][j] = 0: score 0, pref 0, biased length 0
+constexpr int32_t kNegF = (int32_t)(((uint32_t)kNegScore << kScoreShift) | (3u << kPrefShift));
+constexpr int32_t kNegE = (int32_t)((uint32_t)kNegScore << kScoreShift);
+
+struct DpLds {
+    int32_t prof[4 * kProfStride] __attribute__((aligned(16)));
+};
+// prof[c][i] = (adapter[i] == c ? (match-mismatch)<<13 : 0) + diag preference 4; call by all threads,
+// then __syncthreads()
+__device__ __forceinline__ void dp_lds_fill(DpLds &L, const DpParams &dp) {
+    for (int idx = threadIdx.x; idx < 4 * kProfStride; idx += kBlock) {
+        const int c = idx / kProfStride, i = idx % kProfStride;
+        const bool hit = i < 32 && ((dp.eq[c] >> i) & 1u);
+        L.prof[idx] = (int32_t)((hit ? dp.delta : 0u) + (4u << kPrefShift));
+    }
 }
 
-// M = adapter length, compile-time so the row loop is straight-line code with no register moves
+// one DP column: (Hin,Ein) = column j-1, (Hout,Eout) = column j; pc = profile row of the read base
 template <int M>
-__device__ __forceinline__ void dp_align(const uint32_t *__restrict__ row, int n, const DpParams &dp, int &score, int &len) {
-    int32_t Hc[M], Ec[M];
-    const int32_t negv = (int32_t)((uint32_t)kNegScore << kScoreShift);
+__device__ __forceinline__ void dp_column(const int32_t (&Hin)[M], const int32_t (&Ein)[M], int32_t (&Hout)[M],
+                                          int32_t (&Eout)[M], const int32_t *pc, const DpParams &dp, int32_t &hlast) {
+    constexpr int MQ = (M + 3) / 4;
+    int32_t pv[4 * MQ];
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) {
+        const int4 v = reinterpret_cast<const int4 *>(pc)[q];
+        pv[4 * q] = v.x; pv[4 * q + 1] = v.y; pv[4 * q + 2] = v.z; pv[4 * q + 3] = v.w;
+    }
+    int32_t hdiag = kV0, hup = kV0, f1 = kNegF;
 #pragma unroll
     for (int i = 0; i < M; ++i) {
-        // H[i+1][0] = 0, length 0, biased for row i+1; canonical preference 6
-        Hc[i] = (int32_t)(((uint32_t)(-dp.mismatch * (i + 1)) << kScoreShift) | (6u << kPrefShift) | (uint32_t)(kLenBias - (i + 1)));
-        Ec[i] = negv;
+        const int32_t hc = Hin[i], ec = Ein[i];
+        const int32_t e = max(hc + dp.e_open_k, ec + dp.e_ext_k) & kClr;
+        const int32_t f = max(hup + dp.f_open_k, f1 + dp.f_ext_k) | (int32_t)(1u << kPrefShift);
+        const int32_t d = hdiag + pv[i];
+        const int32_t h = max(max(d, f), e) & kClr;
+        hdiag = hc;
+        Hout[i] = h;
+        Eout[i] = e;
+        hup = h;
+        f1 = f;
     }
-    const int32_t v0 = (int32_t)((6u << kPrefShift) | (uint32_t)kLenBias);   // H[0][j] = 0
-    const uint32_t clr = dp.pref_clear;                                       // ~kPrefMask, in an SGPR
-    int32_t pref6 = (int32_t)dp.pref6;                                        // 6<<kPrefShift, in a VGPR
-    asm volatile("" : "+v"(pref6));
-    int32_t best_s = INT32_MIN, best_v = 0;
+    hlast = hup;
+}
+
+template <int M> __device__ __forceinline__ void dp_init(int32_t (&H)[M], int32_t (&E)[M], const DpParams &dp, bool true_boundary) {
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        // H[i+1][0] = 0 with length 0, biased for row i+1; left of a window: -inf
+        const int32_t h0 = (int32_t)(((uint32_t)(-dp.mismatch * (i + 1)) << kScoreShift) | (uint32_t)(kLenBias - (i + 1)));
+        H[i] = true_boundary ? h0 : kNegE;
+        E[i] = kNegE;
+    }
+}
+
+// best over the last row: strict > keeps the smallest column on ties (policy P3)
+__device__ __forceinline__ void dp_track(int32_t hlast, int32_t &best_s, int32_t &best_v) {
+    const int32_t s = hlast >> kScoreShift;
+    if (s > best_s) { best_s = s; best_v = hlast; }
+}
+
+// last row result, then last column rows 1..M-1 (only when the window reaches the read end): a
+// last-column cell replaces only when strictly greater, smallest row on ties
+template <int M>
+__device__ __forceinline__ void dp_result(const int32_t (&H)[M], int32_t best_s, int32_t best_v, bool last_col, const DpParams &dp,
+                                          int &score, int &len) {
+    int bscore = best_s + dp.mismatch * M;
+    int blen = (int)((uint32_t)best_v & kLenMask) + M - kLenBias;
+    if (last_col) {
+#pragma unroll
+        for (int i = 0; i < M - 1; ++i) {
+            const int si = (H[i] >> kScoreShift) + dp.mismatch * (i + 1);
+            if (si > bscore) { bscore = si; blen = (int)((uint32_t)H[i] & kLenMask) + (i + 1) - kLenBias; }
+        }
+    }
+    score = bscore;
+    len = blen;
+}
+
+// full-width DP: every column of the read, 16 bases a dword
+template <int M>
+__device__ __forceinline__ void dp_align(const uint32_t *__restrict__ row, int n, const DpParams &dp, const DpLds &L, int &score, int &len) {
+    int32_t HA[M], EA[M], HB[M], EB[M];
+    dp_init<M>(HA, EA, dp, true);
+    int32_t best_s = INT32_MIN, best_v = 0, hl;
     const int nwords = (n + 15) >> 4;
     uint32_t word_next = nwords > 0 ? row[0] : 0u;
     for (int w = 0; w < nwords; ++w) {
         uint32_t word = word_next;
         if (w + 1 < nwords) word_next = row[w + 1];
         const int kmax = min(16, n - 16 * w);
-        for (int k = 0; k < kmax; ++k) {
-            const uint32_t c = word & 3u;
-            word >>= 2;
-            const uint32_t eq_lo = (c & 1u) ? dp.eq[1] : dp.eq[0];
-            const uint32_t eq_hi = (c & 1u) ? dp.eq[3] : dp.eq[2];
-            const uint32_t eq = (c & 2u) ? eq_hi : eq_lo;
-            int32_t hdiag = v0, hup = v0, f1 = negv;
+        int k = 0;
+        for (; k + 2 <= kmax; k += 2) {
+            dp_column<M>(HA, EA, HB, EB, L.prof + (word & 3u) * kProfStride, dp, hl);
+            dp_track(hl, best_s, best_v);
+            dp_column<M>(HB, EB, HA, EA, L.prof + ((word >> 2) & 3u) * kProfStride, dp, hl);
+            dp_track(hl, best_s, best_v);
+            word >>= 4;
+        }
+        if (k < kmax) {                      // odd tail (only in the last word)
+            dp_column<M>(HA, EA, HB, EB, L.prof + (word & 3u) * kProfStride, dp, hl);
+            dp_track(hl, best_s, best_v);
 #pragma unroll
-            for (int i = 0; i < M; ++i) {
-                const int32_t hc = Hc[i], ec = Ec[i];
-                const int32_t e = max(hc + dp.e_open_k, ec + dp.e_ext_k) & (int32_t)~kPrefMask;
-                const int32_t f = max(hup + dp.f_open_k, f1 + dp.f_ext_k) | (int32_t)(1u << kPrefShift);
-                const int32_t d = v_mad24(__builtin_amdgcn_ubfe(eq, i, 1), dp.delta, hdiag);
-                const int32_t h = v_and_or(max(max(d, f), e), clr, pref6);
-                hdiag = hc;
-                Hc[i] = h;
-                Ec[i] = e;
-                hup = h;
-                f1 = f;
-            }
-            // hup is now H[M][j]; strict > keeps the smallest column on ties (policy P3)
-            const int32_t s = hup >> kScoreShift;
-            if (s > best_s) { best_s = s; best_v = hup; }
+            for (int i = 0; i < M; ++i) { HA[i] = HB[i]; EA[i] = EB[i]; }
         }
     }
     if (nwords == 0) { score = INT32_MIN / 2; len = 0; return; }
-    int bscore = best_s + dp.mismatch * M;
-    int blen = (int)((uint32_t)best_v & kLenMask) + M - kLenBias;
-    // last column, rows 1..M-1: replaces only when strictly greater, smallest row on ties
-#pragma unroll
-    for (int i = 0; i < M - 1; ++i) {
-        const int si = (Hc[i] >> kScoreShift) + dp.mismatch * (i + 1);
-        if (si > bscore) { bscore = si; blen = (int)((uint32_t)Hc[i] & kLenMask) + (i + 1) - kLenBias; }
-    }
-    score = bscore;
-    len = blen;
+    dp_result<M>(HA, best_s, best_v, true, dp, score, len);
 }
 
 // outcome of one alignment task -> spans (+ suffix task for an accepted prefix)
@@ -332,6 +385,8 @@ __global__ __launch_bounds__(kBlock) void k_dp(const uint32_t *__restrict__ rows
                                                const uint32_t *__restrict__ list, const uint32_t *__restrict__ cnt,
                                                uint32_t count_stat, uint64_t *__restrict__ counters) {
     __shared__ FlatList fl;
+    __shared__ DpLds L;
+    dp_lds_fill(L, dp);
     flat_build(fl, cnt, bl.grid);
     const uint32_t total = fl.pre[kMaxGrid];
     const uint32_t n_round = (total + WAVE - 1) / WAVE * WAVE;
@@ -345,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void k_dp(const uint32_t *__restrict__ rows
             n = lens[r];
         }
         int score, len;
-        dp_align<M>(rows + (uint64_t)r * W, n, dp, score, len);
+        dp_align<M>(rows + (uint64_t)r * W, n, dp, L, score, len);
         const bool pushS = dp_commit(valid, r, n, score >= dp.T, len, dp, spans);
         if (dp.is_prefix) push_suffix(bl, seg, r, pushS);
     }
@@ -458,20 +513,9 @@ __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ 
 // column when a == 0, otherwise -inf (every cell left of the window is off all accepting paths)
 template <int M>
 __device__ __forceinline__ void dp_window(const uint32_t *__restrict__ row, int W, int n, int a, int b, const DpParams &dp,
-                                          int &score, int &len) {
-    int32_t Hc[M], Ec[M];
-    const int32_t negv = (int32_t)((uint32_t)kNegScore << kScoreShift);
-    const int32_t negh = negv | (int32_t)(6u << kPrefShift);
-#pragma unroll
-    for (int i = 0; i < M; ++i) {
-        const int32_t h0 = (int32_t)(((uint32_t)(-dp.mismatch * (i + 1)) << kScoreShift) | (6u << kPrefShift) | (uint32_t)(kLenBias - (i + 1)));
-        Hc[i] = a == 0 ? h0 : negh;
-        Ec[i] = negv;
-    }
-    const int32_t v0 = (int32_t)((6u << kPrefShift) | (uint32_t)kLenBias);
-    const uint32_t clr = dp.pref_clear;
-    int32_t pref6 = (int32_t)dp.pref6;
-    asm volatile("" : "+v"(pref6));
+                                          const DpLds &L, int &score, int &len) {
+    int32_t HA[M], EA[M], HB[M], EB[M];
+    dp_init<M>(HA, EA, dp, a == 0);
     // 5 dwords hold the window (phase <= 15 bases + 64 columns = 79 <= 80 bases)
     const int wi = a >> 4;
     uint32_t q0 = wi + 0 < W ? row[wi + 0] : 0u;
@@ -481,49 +525,32 @@ __device__ __forceinline__ void dp_window(const uint32_t *__restrict__ row, int 
     uint32_t q4 = wi + 4 < W ? row[wi + 4] : 0u;
     const uint32_t ph = 2u * (uint32_t)(a & 15);
     q0 = funnel(q1, q0, ph); q1 = funnel(q2, q1, ph); q2 = funnel(q3, q2, ph); q3 = funnel(q4, q3, ph); q4 >>= ph;
-    int32_t best_s = INT32_MIN, best_v = 0;
+    int32_t best_s = INT32_MIN, best_v = 0, hl;
     const int wlen = b - a;
-    for (int t = 0; t < wlen; ++t) {
-        const uint32_t c = q0 & 3u;
-        q0 = funnel(q1, q0, 2); q1 = funnel(q2, q1, 2); q2 = funnel(q3, q2, 2); q3 = funnel(q4, q3, 2); q4 >>= 2;
-        const uint32_t eq_lo = (c & 1u) ? dp.eq[1] : dp.eq[0];
-        const uint32_t eq_hi = (c & 1u) ? dp.eq[3] : dp.eq[2];
-        const uint32_t eq = (c & 2u) ? eq_hi : eq_lo;
-        int32_t hdiag = v0, hup = v0, f1 = negv;
+    int t = 0;
+    for (; t + 2 <= wlen; t += 2) {
+        dp_column<M>(HA, EA, HB, EB, L.prof + (q0 & 3u) * kProfStride, dp, hl);
+        dp_track(hl, best_s, best_v);
+        dp_column<M>(HB, EB, HA, EA, L.prof + ((q0 >> 2) & 3u) * kProfStride, dp, hl);
+        dp_track(hl, best_s, best_v);
+        q0 = funnel(q1, q0, 4); q1 = funnel(q2, q1, 4); q2 = funnel(q3, q2, 4); q3 = funnel(q4, q3, 4); q4 >>= 4;
+    }
+    if (t < wlen) {
+        dp_column<M>(HA, EA, HB, EB, L.prof + (q0 & 3u) * kProfStride, dp, hl);
+        dp_track(hl, best_s, best_v);
 #pragma unroll
-        for (int i = 0; i < M; ++i) {
-            const int32_t hc = Hc[i], ec = Ec[i];
-            const int32_t e = max(hc + dp.e_open_k, ec + dp.e_ext_k) & (int32_t)~kPrefMask;
-            const int32_t f = max(hup + dp.f_open_k, f1 + dp.f_ext_k) | (int32_t)(1u << kPrefShift);
-            const int32_t d = v_mad24(__builtin_amdgcn_ubfe(eq, i, 1), dp.delta, hdiag);
-            const int32_t h = v_and_or(max(max(d, f), e), clr, pref6);
-            hdiag = hc;
-            Hc[i] = h;
-            Ec[i] = e;
-            hup = h;
-            f1 = f;
-        }
-        const int32_t s = hup >> kScoreShift;
-        if (s > best_s) { best_s = s; best_v = hup; }
+        for (int i = 0; i < M; ++i) { HA[i] = HB[i]; EA[i] = EB[i]; }
     }
     if (wlen <= 0) { score = INT32_MIN / 2; len = 0; return; }
-    int bscore = best_s + dp.mismatch * M;
-    int blen = (int)((uint32_t)best_v & kLenMask) + M - kLenBias;
-    if (b == n) {
-#pragma unroll
-        for (int i = 0; i < M - 1; ++i) {
-            const int si = (Hc[i] >> kScoreShift) + dp.mismatch * (i + 1);
-            if (si > bscore) { bscore = si; blen = (int)((uint32_t)Hc[i] & kLenMask) + (i + 1) - kLenBias; }
-        }
-    }
-    score = bscore;
-    len = blen;
+    dp_result<M>(HA, best_s, best_v, b == n, dp, score, len);
 }
 
 template <int M>
 __global__ __launch_bounds__(kBlock) void k_dpw(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
                                                 DpParams dp, short2 *__restrict__ spans, BatchLists bl, int cls) {
     __shared__ FlatList fl;
+    __shared__ DpLds L;
+    dp_lds_fill(L, dp);
     const uint32_t *list = bl.listW[cls], *win = bl.winW[cls];
     flat_build(fl, bl.cntW[cls], bl.grid);
     const uint32_t total = fl.pre[kMaxGrid];
@@ -542,7 +569,7 @@ __global__ __launch_bounds__(kBlock) void k_dpw(const uint32_t *__restrict__ row
             wb = (int)(w >> 16);
         }
         int score, len;
-        dp_window<M>(rows + (uint64_t)r * W, W, n, wa, wb, dp, score, len);
+        dp_window<M>(rows + (uint64_t)r * W, W, n, wa, wb, dp, L, score, len);
         const bool pushS = dp_commit(valid, r, n, score >= dp.T, len, dp, spans);
         if (dp.is_prefix) push_suffix(bl, seg, r, pushS);
     }
