@@ -57,36 +57,38 @@ struct GenericParams {
 };
 
 // ---- device count table ---------------------------------------------------------------------
-// Open addressing, linear probing.  tags[s]==0 <=> empty.  refs[s]==0 <=> key not yet published.
-// ref = off_dwords<<24 | 1<<23 | kind<<16 | len     (len: bytes for kind 0, bases for kind 1)
+// Open addressing, linear probing, one 64-byte slot per key (layout and protocol: vf_kernels.hip).
+// Exported entries: ref = key_off_dwords<<24 | 1<<23 | kind<<16 | len  (len: bytes for kind 0, bases
+// for kind 1), keys compacted into the blob arena.
 constexpr uint64_t kRefValid = 1ull << 23;
-constexpr uint64_t kRefOverflow = ~0ull;
 enum { kKindBytes = 0, kKindPacked = 1 };
 
 enum Counter : int {        // uint64 counters[] in device memory
-    C_ARENA_TOP = 0,        // dwords
+    C_ARENA_TOP = 0,        // dwords of the long-key arena handed out
     C_ENTRIES = 1,
-    C_ERROR = 2,            // bit0 arena full, bit1 table full
-    C_ACCEPTED = 3,
-    C_COUNTED = 4,
-    C_DP_PREFIX = 5,
-    C_DP_SUFFIX = 6,
-    C_EXPORT_N = 7,
-    C_NUM = 8
+    C_ERROR = 2,            // bit0 arena full, bit1 table full, bit2 key too long
+    C_KEY_DWORDS = 3,       // total key dwords of all entries (size of an export)
+    C_ACCEPTED = 4,
+    C_COUNTED = 5,
+    C_DP_PREFIX = 6,
+    C_DP_SUFFIX = 7,
+    C_EXPORT_N = 8,
+    C_EXPORT_KEYS = 9,
+    C_NUM = 10
 };
+constexpr int kTableCounters = 4;       // C_ARENA_TOP..C_KEY_DWORDS are reset with the table
 
 constexpr uint32_t kChunkRows = 17;     // chunk-state rows: 16 batch streams + the main stream
 
 struct Table {
     unsigned long long *chunk_state;  // [kChunkRows][kMaxGrid] workgroup arena chunks (see arena_alloc)
     uint32_t chunk_row;               // row of the launching stream
-    uint32_t *tags;
-    uint64_t *refs;
-    uint64_t *counts;
-    uint32_t *arena;
+    uint4 *slots;                     // 4 x uint4 per slot
+    uint64_t *counts;                 // one per slot, apart from the slot lines
+    uint32_t *arena;                  // long keys only
     uint64_t *counters;
     uint32_t slot_mask;
-    uint64_t arena_cap;     // dwords
+    uint64_t arena_cap;               // dwords
 };
 
 // ---- launchers (vf_kernels.hip) ---------------------------------------------------------------
@@ -112,7 +114,7 @@ hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint1
 hipError_t launch_generic(hipStream_t s, const uint8_t *bytes, const uint64_t *offs, uint64_t n,
                           const GenericParams &gp, int32_t *starts, int32_t *ends, int32_t *ws,
                           uint64_t ws_stride, uint32_t ws_rows, Table t);
-hipError_t launch_export(hipStream_t s, Table t, uint64_t *out_refs, uint64_t *out_counts);
+hipError_t launch_export(hipStream_t s, Table t, uint64_t *out_refs, uint64_t *out_counts, uint32_t *out_arena);
 hipError_t launch_merge(hipStream_t s, Table t, const uint64_t *refs, const uint64_t *counts,
                         const uint32_t *arena, uint64_t n);
 

@@ -196,7 +196,7 @@ struct vf_ctx {
     // table
     Table tab{};
     uint64_t table_slots = 0, arena_dwords = 0;
-    DevBuf<uint32_t> t_tags; DevBuf<uint64_t> t_refs, t_counts; DevBuf<uint32_t> t_arena; DevBuf<uint64_t> t_counters;
+    DevBuf<uint4> t_slots; DevBuf<uint64_t> t_counts; DevBuf<uint32_t> t_arena; DevBuf<uint64_t> t_counters;
     DevBuf<unsigned long long> t_chunks;
     // pipeline
     std::vector<std::unique_ptr<Slot>> slots;
@@ -290,12 +290,11 @@ static void fill_dp(DpParams &d, const std::string &ad, int64_t T, const vf_ctx 
 // create / destroy
 // ------------------------------------------------------------------------------------------------
 static int table_clear_locked(vf_ctx *c, bool all_counters = false) {
-    HIP_TRY(hipMemsetAsync(c->t_tags.p, 0, c->table_slots * sizeof(uint32_t), c->main_stream));
-    HIP_TRY(hipMemsetAsync(c->t_refs.p, 0, c->table_slots * sizeof(uint64_t), c->main_stream));
+    HIP_TRY(hipMemsetAsync(c->t_slots.p, 0, c->table_slots * 64, c->main_stream));
     HIP_TRY(hipMemsetAsync(c->t_counts.p, 0, c->table_slots * sizeof(uint64_t), c->main_stream));
     HIP_TRY(hipMemsetAsync(c->t_chunks.p, 0, (size_t)kChunkRows * kMaxGrid * sizeof(unsigned long long), c->main_stream));
     // arena top, entry count and error bits belong to the table; the read statistics do not
-    HIP_TRY(hipMemsetAsync(c->t_counters.p, 0, (all_counters ? (size_t)C_NUM : 3) * sizeof(uint64_t), c->main_stream));
+    HIP_TRY(hipMemsetAsync(c->t_counters.p, 0, (all_counters ? (size_t)C_NUM : (size_t)kTableCounters) * sizeof(uint64_t), c->main_stream));
     HIP_TRY(hipStreamSynchronize(c->main_stream));
     return VF_OK;
 }
@@ -365,15 +364,15 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     uint64_t pow2 = 1; while (pow2 < slots) pow2 <<= 1;
     if (pow2 > (1ull << 32)) return fail(VF_EINVAL, "table_slots too large");
     c->table_slots = pow2;
-    c->arena_dwords = (p->arena_bytes ? p->arena_bytes : (1ull << 30)) / 4;
-    if ((rc = c->t_tags.ensure(c->table_slots))) return rc;
-    if ((rc = c->t_refs.ensure(c->table_slots))) return rc;
+    c->arena_dwords = (p->arena_bytes ? p->arena_bytes : (1ull << 28)) / 4;
+    if ((rc = c->t_slots.ensure(c->table_slots * 4))) return rc;
     if ((rc = c->t_counts.ensure(c->table_slots))) return rc;
     if ((rc = c->t_arena.ensure(c->arena_dwords))) return rc;
     if ((rc = c->t_counters.ensure(C_NUM))) return rc;
     if ((rc = c->t_chunks.ensure((size_t)kChunkRows * kMaxGrid))) return rc;
     c->tab.chunk_state = c->t_chunks.p; c->tab.chunk_row = kChunkRows - 1;
-    c->tab.tags = c->t_tags.p; c->tab.refs = c->t_refs.p; c->tab.counts = c->t_counts.p;
+    c->tab.slots = c->t_slots.p;
+    c->tab.counts = c->t_counts.p;
     c->tab.arena = c->t_arena.p; c->tab.counters = c->t_counters.p;
     c->tab.slot_mask = (uint32_t)(c->table_slots - 1); c->tab.arena_cap = c->arena_dwords;
     if ((rc = table_clear_locked(c.get(), true))) return rc;
@@ -403,7 +402,7 @@ extern "C" void vf_ctx_destroy(vf_ctx *c) {
         if (s->stream) (void)hipStreamDestroy(s->stream);
     }
     c->resident.release(); c->exp_refs.release(); c->exp_counts.release();
-    c->t_tags.release(); c->t_refs.release(); c->t_counts.release(); c->t_arena.release(); c->t_counters.release(); c->t_chunks.release();
+    c->t_slots.release(); c->t_counts.release(); c->t_arena.release(); c->t_counters.release(); c->t_chunks.release();
     c->d_adapters.release();
     if (c->main_stream) (void)hipStreamDestroy(c->main_stream);
     delete c;
@@ -750,7 +749,7 @@ extern "C" int vf_table_export_size(vf_ctx *c, uint64_t *nbytes) {
     if (rc) return rc;
     uint64_t h[C_NUM];
     if ((rc = check_device_errors(c, h))) return rc;
-    *nbytes = blob_bytes(h[C_ENTRIES], h[C_ARENA_TOP]);
+    *nbytes = blob_bytes(h[C_ENTRIES], h[C_KEY_DWORDS]);
     return VF_OK;
 }
 
@@ -761,19 +760,18 @@ extern "C" int vf_table_export(vf_ctx *c, void *d_dst, uint64_t capacity, uint64
     if (rc) return rc;
     uint64_t h[C_NUM];
     if ((rc = check_device_errors(c, h))) return rc;
-    const uint64_t n = h[C_ENTRIES], adw = h[C_ARENA_TOP];
+    const uint64_t n = h[C_ENTRIES], adw = h[C_KEY_DWORDS];
     const uint64_t need = blob_bytes(n, adw);
     if (capacity < need) return fail(VF_EINVAL, "export buffer too small");
     uint8_t *dst = (uint8_t *)d_dst;
     const uint64_t hdr[2] = {n, adw};
     HIP_TRY(hipMemcpyAsync(dst, hdr, 16, hipMemcpyHostToDevice, c->main_stream));
-    HIP_TRY(hipMemsetAsync(c->t_counters.p + C_EXPORT_N, 0, sizeof(uint64_t), c->main_stream));
-    HIP_TRY(launch_export(c->main_stream, c->tab, (uint64_t *)(dst + 16), (uint64_t *)(dst + 16 + n * 8)));
-    if (adw) HIP_TRY(hipMemcpyAsync(dst + 16 + n * 16, c->t_arena.p, adw * 4, hipMemcpyDeviceToDevice, c->main_stream));
+    HIP_TRY(hipMemsetAsync(c->t_counters.p + C_EXPORT_N, 0, 2 * sizeof(uint64_t), c->main_stream));
+    HIP_TRY(launch_export(c->main_stream, c->tab, (uint64_t *)(dst + 16), (uint64_t *)(dst + 16 + n * 8), (uint32_t *)(dst + 16 + n * 16)));
     HIP_TRY(hipStreamSynchronize(c->main_stream));
-    uint64_t got = 0;
-    HIP_TRY(hipMemcpy(&got, c->t_counters.p + C_EXPORT_N, 8, hipMemcpyDeviceToHost));
-    if (got != n) return fail(VF_EDEVICE, "table export count mismatch");
+    uint64_t got[2] = {0, 0};
+    HIP_TRY(hipMemcpy(got, c->t_counters.p + C_EXPORT_N, 16, hipMemcpyDeviceToHost));
+    if (got[0] != n || got[1] != adw) return fail(VF_EDEVICE, "table export count mismatch");
     if (written) *written = need;
     return VF_OK;
 }
@@ -888,7 +886,7 @@ extern "C" int vf_stats_get(vf_ctx *c, vf_stats *o) {
     o->reads = c->n_reads; o->reads_generic = c->n_generic;
     o->dp_prefix = h[C_DP_PREFIX]; o->dp_suffix = h[C_DP_SUFFIX];
     o->accepted = h[C_ACCEPTED]; o->counted = h[C_COUNTED];
-    o->table_entries = h[C_ENTRIES]; o->arena_dwords = h[C_ARENA_TOP];
+    o->table_entries = h[C_ENTRIES]; o->arena_dwords = h[C_KEY_DWORDS];
     o->ms_scan = c->ms[K_SCAN]; o->ms_dp_prefix = c->ms[K_DPP]; o->ms_dp_suffix = c->ms[K_DPS];
     o->ms_finish = c->ms[K_FIN]; o->ms_generic = c->ms[K_GEN];
     o->launches_scan = c->launches[K_SCAN]; o->launches_dp_prefix = c->launches[K_DPP];

@@ -598,12 +598,19 @@ __device__ __forceinline__ uint32_t key_dwords(uint32_t kind, uint32_t len) {
     return kind == kKindPacked ? (len + 15u) >> 4 : (len + 3u) >> 2;
 }
 
+constexpr int kInlineDwords = 14;        // key dwords held inside the slot
+
 // key held in registers (static indexing)
 template <int ND> struct RegKey {
     const uint32_t (&k)[ND];
     template <class F> __device__ __forceinline__ void each(uint32_t nd, F f) const {
 #pragma unroll
         for (int d = 0; d < ND; ++d) if ((uint32_t)d < nd) f((uint32_t)d, k[d]);
+    }
+    // first kInlineDwords dwords, zero padded (register keys are zero beyond their length)
+    __device__ __forceinline__ void head(uint32_t, uint32_t (&o)[kInlineDwords]) const {
+#pragma unroll
+        for (int d = 0; d < kInlineDwords; ++d) o[d] = d < ND ? k[d < ND ? d : 0] : 0u;
     }
 };
 // key held in memory, element d at p[d*stride]
@@ -613,29 +620,64 @@ struct MemKey {
     template <class F> __device__ __forceinline__ void each(uint32_t nd, F f) const {
         for (uint32_t d = 0; d < nd; ++d) f(d, p[d * stride]);
     }
+    __device__ __forceinline__ void head(uint32_t nd, uint32_t (&o)[kInlineDwords]) const {
+#pragma unroll
+        for (int d = 0; d < kInlineDwords; ++d) o[d] = (uint32_t)d < nd ? p[d * stride] : 0u;
+    }
 };
 
-// ---- workgroup-local arena allocator ---------------------------------------------------------------
-// New keys take their arena space from a chunk owned by the workgroup; only a chunk refill touches
-// the global bump pointer (a per-key atomicAdd on one address serialised at ~7 ns per new key and
-// dominated k_finish).  The chunk state survives across launches in t.chunk_state[row][block], one
-// row per stream, so the arena loses at most one partial chunk per (stream, workgroup) in total.
+// ---- device count table: one 64-byte slot per key ---------------------------------------------------
+//   slot = { u64 w0; u32 key[14] }                       (a lookup touches exactly one 64-byte line)
+//   w0   = tag | len<<32 | kind<<48 | LONG<<50 | OVF<<51 | READY<<63 ;  0 = empty
+// Keys of up to 14 dwords (56 peptide letters / 224 bases) live in the slot, zero padded, so a probe
+// compares all 14 dwords without predication.  Longer keys (LONG) keep their arena offset in key[0..1].
+// Counts sit in their own array: atomics execute at the memory side and drop the line from L2, so a
+// count sharing the slot's line made every probe of a hot key miss L2 (measured 3x slower).
+// Protocol: claim by 64-bit CAS on w0 (READY clear), write the key, s_waitcnt vmcnt(0), store w0|READY.
+// Every word another workgroup may read is written and read with agent-scope (sc1) accesses; all of
+// them are write-once, so a stale view can only ever cause a duplicate entry, never a false match
+// (the host sums duplicate strings when it builds the result).  A negative compare is only believed
+// when it comes from a load issued after READY had already been observed.
+constexpr uint64_t kW0Ready = 1ull << 63, kW0Long = 1ull << 50, kW0Ovf = 1ull << 51;
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+
+__device__ __forceinline__ void slot_load(const uint4 *p, uint4 &a, uint4 &b, uint4 &c, uint4 &d) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                 "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
+                 "global_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p) : "memory");
+}
+__device__ __forceinline__ unsigned long long *slot_count(const Table &t, uint32_t slot) {
+    return reinterpret_cast<unsigned long long *>(t.counts) + slot;
+}
+
+// ---- workgroup-local state: arena chunks for LONG keys, insert counters --------------------------
+// LONG keys take arena space from a chunk owned by the workgroup; only a refill touches the global
+// bump pointer.  The chunk state survives across launches in t.chunk_state[row][block], one row per
+// stream, so the arena loses at most one partial chunk per (stream, workgroup) in total.
 //   state = (chunk_index + 1) << 32 | dwords_used      (0 = no chunk yet)
 constexpr uint32_t kChunk = 4096;            // dwords
 struct BlockTable {
     unsigned long long chunk;                // LDS copy of the chunk state
     uint32_t new_entries;                    // keys inserted by this workgroup (flushed at kernel end)
+    uint32_t new_key_dwords;                 // their total key dwords
 };
 __device__ __forceinline__ void block_table_begin(BlockTable &bt, const Table &t) {
     if (threadIdx.x == 0) {
         bt.chunk = t.chunk_state[(uint64_t)t.chunk_row * kMaxGrid + blockIdx.x];
         bt.new_entries = 0;
+        bt.new_key_dwords = 0;
     }
 }
 __device__ __forceinline__ void block_table_end(BlockTable &bt, const Table &t) {     // after a __syncthreads()
     if (threadIdx.x == 0) {
         t.chunk_state[(uint64_t)t.chunk_row * kMaxGrid + blockIdx.x] = bt.chunk;
-        if (bt.new_entries) atomicAdd((unsigned long long *)&t.counters[C_ENTRIES], (unsigned long long)bt.new_entries);
+        if (bt.new_entries) {
+            atomicAdd((unsigned long long *)&t.counters[C_ENTRIES], (unsigned long long)bt.new_entries);
+            atomicAdd((unsigned long long *)&t.counters[C_KEY_DWORDS], (unsigned long long)bt.new_key_dwords);
+        }
     }
 }
 enum { kAllocRetry = 0, kAllocOk = 1, kAllocFull = 2 };
@@ -660,11 +702,7 @@ __device__ __forceinline__ int arena_alloc(BlockTable &bt, const Table &t, uint3
     return kAllocOk;
 }
 
-// Finds key's slot, inserting the key if absent; returns kNoSlot on a capacity error.  Every word
-// another workgroup may read is written and read with agent-scope (sc1) atomics; write-once words +
-// the publish order tag -> key -> ref mean a stale view can only ever cause a duplicate entry, never
-// a false match (the host merges duplicates when it builds the result).
-constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+// Finds key's slot, inserting the key if absent; returns kNoSlot on a capacity error.
 template <class K>
 __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTable &bt, const K &key, uint32_t kind, uint32_t len, bool active) {
     uint32_t found = kNoSlot;
@@ -674,62 +712,86 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
     hash_init(h, meta);
     key.each(nd, [&](uint32_t, uint32_t v) { hash_step(h, v); });
     hash_fin(h);
-    const uint32_t tag = h.h2;
+    const bool is_long = nd > (uint32_t)kInlineDwords;
+    const uint64_t w0mine = (uint64_t)h.h2 | ((uint64_t)meta << 32) | (is_long ? kW0Long : 0ull);
+    uint32_t kin[kInlineDwords];
+    key.head(nd, kin);
     uint32_t slot = h.h1 & t.slot_mask;
     uint32_t probes = 0;
     bool done = !active;
-    bool claimed = false;                    // this lane won the slot's tag and must publish its key
+    bool claimed = false;                    // this lane won the slot and must publish its key
+    bool confirmed = false;                  // READY already seen at this slot (a mismatch is now final)
     // The loop condition is a wave-wide vote: no lane leaves before every lane is done.  A lane that
     // finds a slot claimed but not yet published simply looks again on the next trip; because the
     // claiming lane (possibly in this very wave) publishes inside the loop body, before the vote,
     // the wait cannot deadlock and the compiler cannot sink the publish past the loop exit.
     while (__any(!done)) {
         if (!done) {
+            uint4 *sp = t.slots + (uint64_t)slot * 4;
             bool advance = false;
-            uint32_t tg = tag;
+            uint4 l0 = make_uint4(0, 0, 0, 0), l1 = l0, l2 = l0, l3 = l0;
+            uint64_t w0 = 0;
             if (!claimed) {
-                tg = ld_agent(&t.tags[slot]);
-                if (tg == 0u) {
-                    tg = atomicCAS(&t.tags[slot], 0u, tag);
-                    claimed = tg == 0u;
+                slot_load(sp, l0, l1, l2, l3);
+                w0 = (uint64_t)l0.x | ((uint64_t)l0.y << 32);
+                if (w0 == 0ull) {
+                    w0 = atomicCAS(reinterpret_cast<unsigned long long *>(sp), 0ull, (unsigned long long)w0mine);
+                    claimed = w0 == 0ull;
                 }
             }
             if (claimed) {
-                uint64_t off = 0;
-                const int rc = arena_alloc(bt, t, nd, off);
-                if (rc == kAllocOk) {
-                    key.each(nd, [&](uint32_t d, uint32_t v) { st_agent(&t.arena[off + d], v); });
+                unsigned long long *kw = reinterpret_cast<unsigned long long *>(sp) + 1;
+                if (!is_long) {
+#pragma unroll
+                    for (int d = 0; d < kInlineDwords; d += 2) st_agent(kw + d / 2, (unsigned long long)kin[d] | ((unsigned long long)kin[d + 1] << 32));
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    st_agent(&t.refs[slot], (off << 24) | kRefValid | (uint64_t)meta);
+                    st_agent(reinterpret_cast<unsigned long long *>(sp), (unsigned long long)(w0mine | kW0Ready));
                     atomicAdd(&bt.new_entries, 1u);
+                    atomicAdd(&bt.new_key_dwords, nd);
                     found = slot;
                     done = true;
-                } else if (rc == kAllocFull) {
-                    atomicOr((unsigned long long *)&t.counters[C_ERROR], 1ull);
-                    st_agent(&t.refs[slot], kRefOverflow);
-                    done = true;
+                } else {
+                    uint64_t off = 0;
+                    const int rc = arena_alloc(bt, t, nd, off);
+                    if (rc == kAllocOk) {
+                        key.each(nd, [&](uint32_t d, uint32_t v) { st_agent(&t.arena[off + d], v); });
+                        st_agent(kw, (unsigned long long)off);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        st_agent(reinterpret_cast<unsigned long long *>(sp), (unsigned long long)(w0mine | kW0Ready));
+                        atomicAdd(&bt.new_entries, 1u);
+                        atomicAdd(&bt.new_key_dwords, nd);
+                        found = slot;
+                        done = true;
+                    } else if (rc == kAllocFull) {
+                        atomicOr((unsigned long long *)&t.counters[C_ERROR], 1ull);
+                        st_agent(reinterpret_cast<unsigned long long *>(sp), (unsigned long long)(w0mine | kW0Ready | kW0Ovf));
+                        done = true;
+                    }
                 }
-            } else if (tg == tag) {
-                const uint64_t ref = ld_agent(&t.refs[slot]);
-                if (ref == 0ull) {
+            } else if ((w0 & ~(kW0Ready | kW0Ovf)) == w0mine) {
+                if (!(w0 & kW0Ready)) {
                     // claimed by another lane, key not yet published: look at the same slot again next trip
-                } else if (ref == kRefOverflow) {
+                } else if (w0 & kW0Ovf) {
                     done = true;
                 } else {
-                    bool same = (uint32_t)(ref & 0x3FFFFull) == meta;
-                    if (same) {
-                        const uint64_t off = ref >> 24;
-                        uint32_t diff = 0;
+                    uint32_t diff = 0;
+                    if (!is_long) {
+                        diff = (l0.z ^ kin[0]) | (l0.w ^ kin[1]) | (l1.x ^ kin[2]) | (l1.y ^ kin[3]) | (l1.z ^ kin[4]) | (l1.w ^ kin[5]) |
+                               (l2.x ^ kin[6]) | (l2.y ^ kin[7]) | (l2.z ^ kin[8]) | (l2.w ^ kin[9]) | (l3.x ^ kin[10]) | (l3.y ^ kin[11]) |
+                               (l3.z ^ kin[12]) | (l3.w ^ kin[13]);
+                    } else {
+                        const uint64_t off = (uint64_t)l0.z | ((uint64_t)l0.w << 32);
                         key.each(nd, [&](uint32_t d, uint32_t v) { diff |= ld_agent(&t.arena[off + d]) ^ v; });
-                        same = diff == 0u;
                     }
-                    if (same) { found = slot; done = true; }
+                    if (diff == 0u) { found = slot; done = true; }
+                    else if (!confirmed && !is_long) confirmed = true;      // re-read once now that READY is known
                     else advance = true;
                 }
             } else {
                 advance = true;
             }
             if (advance) {
+                confirmed = false;
                 slot = (slot + 1u) & t.slot_mask;
                 if (++probes > t.slot_mask) {
                     atomicOr((unsigned long long *)&t.counters[C_ERROR], 2ull);
@@ -744,7 +806,7 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
 template <class K>
 __device__ __forceinline__ void table_add(const Table &t, BlockTable &bt, const K &key, uint32_t kind, uint32_t len, uint64_t cnt, bool active) {
     const uint32_t slot = table_find_or_insert(t, bt, key, kind, len, active);
-    if (slot != kNoSlot) atomicAdd((unsigned long long *)&t.counts[slot], (unsigned long long)cnt);
+    if (slot != kNoSlot) atomicAdd(slot_count(t, slot), (unsigned long long)cnt);
 }
 
 // Workgroup-level count aggregation: a small LDS table keyed by slot index collects the +1s of a
@@ -766,11 +828,11 @@ __device__ __forceinline__ void agg_add(Agg &a, const Table &t, uint32_t slot) {
     uint32_t cur = *(volatile uint32_t *)&a.slot[i];
     if (cur == kNoSlot) { cur = atomicCAS(&a.slot[i], kNoSlot, slot); if (cur == kNoSlot) cur = slot; }
     if (cur == slot) atomicAdd(&a.cnt[i], 1u);
-    else atomicAdd((unsigned long long *)&t.counts[slot], 1ull);
+    else atomicAdd(slot_count(t, slot), 1ull);
 }
 __device__ __forceinline__ void agg_flush(Agg &a, const Table &t) {
     for (int i = threadIdx.x; i < kAggSize; i += kBlock)
-        if (a.slot[i] != kNoSlot && a.cnt[i]) atomicAdd((unsigned long long *)&t.counts[a.slot[i]], (unsigned long long)a.cnt[i]);
+        if (a.slot[i] != kNoSlot && a.cnt[i]) atomicAdd(slot_count(t, a.slot[i]), (unsigned long long)a.cnt[i]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1044,16 +1106,54 @@ __global__ __launch_bounds__(kBlock) void k_generic(const uint8_t *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 // table export (compaction) and merge (multi-GPU exchange)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_export(Table t, uint64_t *__restrict__ out_refs, uint64_t *__restrict__ out_counts) {
+__global__ __launch_bounds__(kBlock) void k_export(Table t, uint64_t *__restrict__ out_refs, uint64_t *__restrict__ out_counts,
+                                                   uint32_t *__restrict__ out_arena) {
     const uint64_t nslots = (uint64_t)t.slot_mask + 1;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t s = (uint64_t)blockIdx.x * kBlock + threadIdx.x; s < nslots; s += stride) {
-        if (t.tags[s] != 0u) {
-            const uint64_t ref = t.refs[s];
-            if (ref != 0ull && ref != kRefOverflow) {
-                const uint64_t i = atomicAdd((unsigned long long *)&t.counters[C_EXPORT_N], 1ull);
-                out_refs[i] = ref;
-                out_counts[i] = t.counts[s];
+    for (uint64_t s0 = (uint64_t)blockIdx.x * kBlock; s0 < nslots; s0 += stride) {
+        const uint64_t s = s0 + threadIdx.x;
+        uint4 l0 = make_uint4(0, 0, 0, 0), l1 = l0, l2 = l0, l3 = l0;
+        bool live = false;
+        if (s < nslots) {
+            const uint4 *sp = t.slots + s * 4;
+            l0 = sp[0];
+            const uint64_t w0 = (uint64_t)l0.x | ((uint64_t)l0.y << 32);
+            live = (w0 & kW0Ready) && !(w0 & kW0Ovf);
+            if (live) { l1 = sp[1]; l2 = sp[2]; l3 = sp[3]; }
+        }
+        const uint64_t m = __ballot(live);
+        if (!m) continue;
+        const uint64_t w0 = (uint64_t)l0.x | ((uint64_t)l0.y << 32);
+        const uint32_t meta = (uint32_t)(w0 >> 32) & 0x3FFFFu;
+        const uint32_t nd = live ? key_dwords(meta >> 16, meta & 0xFFFFu) : 0u;
+        // wave prefix sums: entry rank and key offset
+        uint32_t incl = nd;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if ((int)lane_id() >= d) incl += up;
+        }
+        const uint32_t total = __shfl(incl, WAVE - 1);
+        const uint32_t leader = __ffsll((unsigned long long)m) - 1;
+        uint64_t base_e = 0, base_k = 0;
+        if (lane_id() == leader) {
+            base_e = atomicAdd((unsigned long long *)&t.counters[C_EXPORT_N], (unsigned long long)__popcll(m));
+            base_k = atomicAdd((unsigned long long *)&t.counters[C_EXPORT_KEYS], (unsigned long long)total);
+        }
+        base_e = __shfl(base_e, leader);
+        base_k = __shfl(base_k, leader);
+        if (live) {
+            const uint64_t e = base_e + __popcll(m & ((1ull << lane_id()) - 1ull));
+            const uint64_t ko = base_k + (incl - nd);
+            out_refs[e] = (ko << 24) | kRefValid | (uint64_t)meta;
+            out_counts[e] = t.counts[s];
+            if (w0 & kW0Long) {
+                const uint64_t off = (uint64_t)l0.z | ((uint64_t)l0.w << 32);
+                for (uint32_t d = 0; d < nd; ++d) out_arena[ko + d] = t.arena[off + d];
+            } else {
+                const uint32_t kk[kInlineDwords] = {l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w, l3.x, l3.y, l3.z, l3.w};
+#pragma unroll
+                for (int d = 0; d < kInlineDwords; ++d) if ((uint32_t)d < nd) out_arena[ko + d] = kk[d];
             }
         }
     }
@@ -1203,9 +1303,9 @@ hipError_t launch_generic(hipStream_t s, const uint8_t *bytes, const uint64_t *o
     return hipGetLastError();
 }
 
-hipError_t launch_export(hipStream_t s, Table t, uint64_t *out_refs, uint64_t *out_counts) {
+hipError_t launch_export(hipStream_t s, Table t, uint64_t *out_refs, uint64_t *out_counts, uint32_t *out_arena) {
     const int g = grid_for((uint64_t)t.slot_mask + 1, 8);
-    hipLaunchKernelGGL(k_export, dim3(g), dim3(kBlock), 0, s, t, out_refs, out_counts);
+    hipLaunchKernelGGL(k_export, dim3(g), dim3(kBlock), 0, s, t, out_refs, out_counts, out_arena);
     return hipGetLastError();
 }
 
