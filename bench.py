@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget (core-seconds) of the baseline sample")
+    ap.add_argument("--table-slots", type=int, default=0, help="count-table slots (0 = 2x the variant library, power of two)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -83,8 +84,8 @@ def main():
     del rows_h, lens_h
     torch.cuda.synchronize(dev)
 
-    slots = 1 << 22
-    while slots < 4 * min(args.variants, n):
+    slots = args.table_slots or (1 << 16)
+    while not args.table_slots and slots < 2 * min(args.variants, n):       # load factor <= 0.5 at worst
         slots <<= 1
     eng = vfind_amd.Engine(ads, device=local_rank, table_slots=slots, arena_bytes=1 << 30)
 

@@ -54,9 +54,9 @@ typedef struct vf_params {
     uint32_t queue_len;              /* batches in flight per GPU (lib.rs:179), default 2 */
     int32_t skip_translation;        /* lib.rs:180 */
     int32_t device;                  /* HIP device ordinal */
-    uint64_t table_slots;            /* count-table slots, power of two; 0 = default (2^24) */
-    uint64_t arena_bytes;            /* key arena bytes; 0 = default (1 GiB) */
-    uint32_t batch_reads;            /* reads per device batch; 0 = default (2^20) */
+    uint64_t table_slots;            /* count-table slots (64 B + 8 B each), power of two; 0 = 2^24 */
+    uint64_t arena_bytes;            /* arena for keys longer than 56 bytes; 0 = 256 MiB */
+    uint32_t batch_reads;            /* reads per device batch; 0 = 2^18 */
     uint32_t reserved;
 } vf_params;
 
@@ -72,7 +72,7 @@ typedef struct vf_stats {
     uint64_t accepted;         /* reads with start < end                                 */
     uint64_t counted;          /* reads that incremented a key (after the len%3 drop)    */
     uint64_t table_entries;    /* distinct keys on the device                            */
-    uint64_t arena_dwords;     /* key arena use                                          */
+    uint64_t arena_dwords;     /* total key dwords held by the table                     */
     /* device time per kernel, milliseconds, summed over launches (HIP events on the
        context's stream; filled only while profiling is on) */
     double ms_scan, ms_dp_prefix, ms_dp_suffix, ms_finish, ms_generic;
@@ -125,7 +125,8 @@ const uint64_t *vf_result_key_offsets(const vf_result *r); /* rows+1 offsets    
 const uint64_t *vf_result_counts(const vf_result *r);      /* rows counts (UInt64)     */
 void vf_result_free(vf_result *r);
 
-/* Empties the device count table (a new find_variants call on a reused context). */
+/* Empties the device count table (a new find_variants call on a reused context).  Asynchronous:
+ * ordered after every batch already submitted and before everything submitted afterwards. */
 int vf_table_clear(vf_ctx *ctx);
 
 /* Multi-GPU exchange of the (key,count) table (the reduce of lib.rs:292-306 across GPUs).

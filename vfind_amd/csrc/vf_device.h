@@ -36,6 +36,8 @@ struct DpParams {
     uint32_t is_prefix;
     uint32_t independent; // 1 = test hook: run the suffix DP even when the prefix failed (lib.rs:278-286)
     int32_t kerr;         // max unit edits of an acceptable alignment (pre-DP filter); <0 = none can pass
+    uint32_t eq_top[4];   // eq[c] moved to the top m bits, low 32-m bits set (Myers filter)
+    uint32_t pv_init;     // top m bits set
 };
 
 struct ScanParams {
@@ -94,9 +96,10 @@ struct Table {
 // ---- launchers (vf_kernels.hip) ---------------------------------------------------------------
 struct BatchLists {        // per in-flight batch; lists are segmented per workgroup of k_scan
     uint32_t *listP, *listS;          // DP tasks per adapter (grid*seg entries each)
-    uint32_t *listW[3], *winW[3];     // filter output: windowed tasks by window-length class (+ a | b<<16)
-    uint32_t *listF;                  // filter output: tasks whose window exceeds the window kernel
-    uint32_t *cntP, *cntS, *cntW[3], *cntF;   // kMaxGrid entries each
+    uint32_t *listW[4], *winW[4];     // filter output: windowed tasks by class (+ window a | b<<16)
+    uint32_t *winW2;                  // second window of class-3 (two-window) tasks
+    uint32_t *listF;                  // filter output: tasks only the full-width DP can take
+    uint32_t *cntP, *cntS, *cntW[4], *cntF;   // kMaxGrid entries each
     uint32_t grid, seg;               // from scan_geometry(n)
 };
 

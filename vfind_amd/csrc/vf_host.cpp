@@ -133,7 +133,7 @@ template <typename T> struct PinBuf {
 
 struct Workspace {               // device scratch of one in-flight batch
     DevBuf<short2> spans;
-    DevBuf<uint32_t> listP, listS, listW[3], winW[3], listF, cnt;
+    DevBuf<uint32_t> listP, listS, listW[4], winW[4], winW2, listF, cnt;
     int ensure(size_t n) {
         int rc;
         uint32_t g, seg;
@@ -141,16 +141,17 @@ struct Workspace {               // device scratch of one in-flight batch
         if ((rc = spans.ensure(n))) return rc;
         if ((rc = listP.ensure((size_t)g * seg))) return rc;
         if ((rc = listS.ensure((size_t)g * seg))) return rc;
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < 4; ++q) {
             if ((rc = listW[q].ensure((size_t)g * seg))) return rc;
             if ((rc = winW[q].ensure((size_t)g * seg))) return rc;
         }
+        if ((rc = winW2.ensure((size_t)g * seg))) return rc;
         if ((rc = listF.ensure((size_t)g * seg))) return rc;
-        return cnt.ensure(6 * kMaxGrid);
+        return cnt.ensure(7 * kMaxGrid);
     }
     void release() {
-        spans.release(); listP.release(); listS.release(); listF.release(); cnt.release();
-        for (int q = 0; q < 3; ++q) { listW[q].release(); winW[q].release(); }
+        spans.release(); listP.release(); listS.release(); listF.release(); winW2.release(); cnt.release();
+        for (int q = 0; q < 4; ++q) { listW[q].release(); winW[q].release(); }
     }
 };
 
@@ -203,6 +204,7 @@ struct vf_ctx {
     std::mutex mu;
     std::condition_variable cv;
     hipStream_t main_stream = nullptr;
+    hipEvent_t clear_event = nullptr;   // recorded on main_stream after each table clear
     Workspace resident;          // for vf_process_device_packed
     DevBuf<uint64_t> exp_refs, exp_counts;
     // stats / profiling
@@ -284,6 +286,9 @@ static void fill_dp(DpParams &d, const std::string &ad, int64_t T, const vf_ctx 
     d.is_prefix = is_prefix ? 1u : 0u;
     d.independent = 0;
     d.kerr = max_unit_errors(T, ad.size(), c.match, c.mismatch, c.gopen, c.gext);
+    const uint32_t up = 32u - d.m;                     // d.m in 1..32
+    for (int q = 0; q < 4; ++q) d.eq_top[q] = up ? ((d.eq[q] << up) | ((1u << up) - 1u)) : d.eq[q];
+    d.pv_init = up ? (0xFFFFFFFFu << up) : 0xFFFFFFFFu;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -295,7 +300,8 @@ static int table_clear_locked(vf_ctx *c, bool all_counters = false) {
     HIP_TRY(hipMemsetAsync(c->t_chunks.p, 0, (size_t)kChunkRows * kMaxGrid * sizeof(unsigned long long), c->main_stream));
     // arena top, entry count and error bits belong to the table; the read statistics do not
     HIP_TRY(hipMemsetAsync(c->t_counters.p, 0, (all_counters ? (size_t)C_NUM : (size_t)kTableCounters) * sizeof(uint64_t), c->main_stream));
-    HIP_TRY(hipStreamSynchronize(c->main_stream));
+    // batch streams order their next table access after this clear through the event (no host sync)
+    HIP_TRY(hipEventRecord(c->clear_event, c->main_stream));
     return VF_OK;
 }
 
@@ -335,6 +341,7 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     if (c->dev < 0 || c->dev >= ndev) return fail(VF_EINVAL, "device ordinal out of range");
     HIP_TRY(hipSetDevice(c->dev));
     HIP_TRY(hipStreamCreateWithFlags(&c->main_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->clear_event, hipEventDisableTiming));
 
     // adapters on the device (byte-wise kernel)
     const size_t alen = c->pre.size() + c->suf.size();
@@ -404,6 +411,7 @@ extern "C" void vf_ctx_destroy(vf_ctx *c) {
     c->resident.release(); c->exp_refs.release(); c->exp_counts.release();
     c->t_slots.release(); c->t_counts.release(); c->t_arena.release(); c->t_counters.release(); c->t_chunks.release();
     c->d_adapters.release();
+    if (c->clear_event) (void)hipEventDestroy(c->clear_event);
     if (c->main_stream) (void)hipStreamDestroy(c->main_stream);
     delete c;
 }
@@ -450,7 +458,8 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
     BatchLists bl{};
     bl.listP = ws.listP.p; bl.listS = ws.listS.p; bl.listF = ws.listF.p;
     bl.cntP = ws.cnt.p; bl.cntS = ws.cnt.p + kMaxGrid; bl.cntF = ws.cnt.p + 2 * kMaxGrid;
-    for (int q = 0; q < 3; ++q) { bl.listW[q] = ws.listW[q].p; bl.winW[q] = ws.winW[q].p; bl.cntW[q] = ws.cnt.p + (3 + q) * kMaxGrid; }
+    bl.winW2 = ws.winW2.p;
+    for (int q = 0; q < 4; ++q) { bl.listW[q] = ws.listW[q].p; bl.winW[q] = ws.winW[q].p; bl.cntW[q] = ws.cnt.p + (3 + q) * kMaxGrid; }
     scan_geometry(n, &bl.grid, &bl.seg);
     // counting mode skips the suffix alignment of a read whose prefix failed (same table, less work);
     // the spans test hook keeps the two searches independent, as find_adapter_match is called (lib.rs:278-286)
@@ -538,6 +547,7 @@ static int submit_chunk(vf_ctx *c, const uint8_t *base, const ReadRef *reads, ui
     struct Rel { vf_ctx *c; Slot *s; ~Rel() { release_slot(c, s); } } rel{c, s};
     int rc;
     if ((rc = wait_slot(s))) return rc;
+    HIP_TRY(hipStreamWaitEvent(s->stream, c->clear_event, 0));
 
     // geometry of the fast part
     uint32_t max_fast = 0;
@@ -674,6 +684,7 @@ extern "C" int vf_submit_packed(vf_ctx *c, const uint32_t *rows, uint32_t W, con
         struct Rel { vf_ctx *c; Slot *s; ~Rel() { release_slot(c, s); } } rel{c, s};
         int rc;
         if ((rc = wait_slot(s))) return rc;
+        HIP_TRY(hipStreamWaitEvent(s->stream, c->clear_event, 0));
         if ((rc = s->h_rows.ensure((size_t)m * W))) return rc;
         if ((rc = s->h_lens.ensure(m))) return rc;
         memcpy(s->h_rows.p, rows + lo * W, (size_t)m * W * 4);
@@ -734,10 +745,13 @@ extern "C" int vf_sync(vf_ctx *c) {
 // ------------------------------------------------------------------------------------------------
 // table: clear / export / merge / finish
 // ------------------------------------------------------------------------------------------------
+// Asynchronous: ordered after every batch already submitted (device-side event waits) and before
+// everything submitted afterwards; the host does not block.
 extern "C" int vf_table_clear(vf_ctx *c) {
     if (!c) return fail(VF_EINVAL, "null context");
-    int rc = vf_sync(c);
-    if (rc && rc != VF_ECAPACITY) return rc;
+    HIP_TRY(hipSetDevice(c->dev));
+    for (auto &s : c->slots)
+        if (s->in_flight) HIP_TRY(hipStreamWaitEvent(c->main_stream, s->done, 0));
     return table_clear_locked(c);
 }
 

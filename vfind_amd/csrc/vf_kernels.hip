@@ -421,60 +421,79 @@ __global__ __launch_bounds__(kBlock) void k_dp(const uint32_t *__restrict__ rows
 // on an accepting path), so the DP restricted to that window returns the same score, end cell and
 // length whenever the full DP would accept, and rejects whenever it would reject.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int n, const DpParams &dp, int &jmin, int &jmax) {
-    uint32_t Pv = 0xFFFFFFFFu, Mv = 0u;
+// The adapter sits in the TOP m bits of the 32-bit state words (so its last row is bit 31) and the
+// low 32-m bits of every Eq mask are ones, which keeps those bits of Pv/Mv/Ph/Mh zero: no masking,
+// and "shift in 0" at the adapter's first row is the free-start boundary of approximate searching.
+// All per-column work is full-rate VALU (and/or/xor/add/not/shift) plus one LDS read of Eq.
+// Detections are collected as one "miss" bit per column and turned into at most two clusters of end
+// columns; clusters further apart than m + kerr have disjoint windows.
+struct Clusters { int ncl, jmin1, jmax1, jmin2, jmax2; };
+
+__device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int n, const DpParams &dp, const uint32_t *s_eq,
+                                           Clusters &cl) {
+    uint32_t Pv = dp.pv_init, Mv = 0u;
     int sc = (int)dp.m;
-    const uint32_t hs = dp.m - 1u;
-    jmin = 0x7FFFFFFF;
-    jmax = 0;
+    const int gap = (int)dp.m + dp.kerr;
+    cl.ncl = 0; cl.jmin1 = 0; cl.jmax1 = 0; cl.jmin2 = 0; cl.jmax2 = 0;
     const int nwords = (n + 15) >> 4;
     uint32_t word_next = nwords > 0 ? row[0] : 0u;
     for (int w = 0; w < nwords; ++w) {
         uint32_t word = word_next;
         if (w + 1 < nwords) word_next = row[w + 1];
         const int kmax = min(16, n - 16 * w);
+        uint32_t miss = 0;
         for (int k = 0; k < kmax; ++k) {
-            const uint32_t c = word & 3u;
+            const uint32_t Eq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_eq) + ((word & 3u) << 2));
             word >>= 2;
-            const uint32_t eq_lo = (c & 1u) ? dp.eq[1] : dp.eq[0];
-            const uint32_t eq_hi = (c & 1u) ? dp.eq[3] : dp.eq[2];
-            const uint32_t Eq = (c & 2u) ? eq_hi : eq_lo;
             const uint32_t Xv = Eq | Mv;
             const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
             uint32_t Ph = Mv | ~(Xh | Pv);
             uint32_t Mh = Pv & Xh;
-            sc += (int)((Ph >> hs) & 1u) - (int)((Mh >> hs) & 1u);
+            sc += (int)(Ph >> 31) - (int)(Mh >> 31);
             Ph <<= 1;
             Mh <<= 1;
             Pv = Mh | ~(Xv | Ph);
             Mv = Ph & Xv;
-            if (sc <= dp.kerr) {
-                const int j = 16 * w + k + 1;
-                jmin = min(jmin, j);
-                jmax = j;
-            }
+            miss = (miss << 1) | ((uint32_t)(dp.kerr - sc) >> 31);
+        }
+        uint32_t det = ~miss & ((1u << kmax) - 1u);     // bit kmax-1-k <=> column 16w+k+1 detected
+        while (det) {
+            const int hb = 31 - __clz((int)det);
+            det &= ~(1u << hb);
+            const int j = 16 * w + (kmax - 1 - hb) + 1;
+            if (cl.ncl == 0) { cl.ncl = 1; cl.jmin1 = j; cl.jmax1 = j; }
+            else if (cl.ncl == 1) { if (j - cl.jmax1 > gap) { cl.ncl = 2; cl.jmin2 = j; cl.jmax2 = j; } else cl.jmax1 = j; }
+            else if (cl.ncl == 2) { if (j - cl.jmax2 > gap) cl.ncl = 3; else cl.jmax2 = j; }
         }
     }
 }
 
 constexpr int kMaxWindow = 64;   // columns the windowed DP holds in registers (5 dwords incl. phase)
-// window-length classes: tasks of similar trip count share waves (a wave runs its longest window)
-__device__ __forceinline__ int window_class(int wl, int base) {
-    if (wl <= base + 8) return 0;
-    if (wl <= base + 20) return 1;
-    return wl <= kMaxWindow ? 2 : 3;           // 3 = wider than the window kernel holds -> full-width DP
+// Window classes: tasks of similar trip count share waves (a wave runs its longest window).
+//   0..2 one window by length, 3 two disjoint windows, 4 anything else -> full-width DP
+__device__ __forceinline__ int window_class(const Clusters &cl, int a1, int a2, int base) {
+    const int w1 = cl.jmax1 - a1, w2 = cl.jmax2 - a2;
+    if (cl.ncl == 1) {
+        if (w1 <= base + 8) return 0;
+        if (w1 <= base + 20) return 1;
+        return w1 <= kMaxWindow ? 2 : 4;
+    }
+    if (cl.ncl == 2 && w1 <= kMaxWindow && w2 <= kMaxWindow) return 3;
+    return 4;
 }
 
 __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
                                                    DpParams dp, short2 *__restrict__ spans, BatchLists bl,
                                                    uint64_t *__restrict__ counters) {
-    __shared__ uint32_t s_c[4];
+    __shared__ uint32_t s_c[5];
+    __shared__ uint32_t s_eq[4];
+    if (threadIdx.x < 4) s_eq[threadIdx.x] = dp.eq_top[threadIdx.x];
     const uint32_t *list = dp.is_prefix ? bl.listP : bl.listS;
     const uint32_t *cnt = dp.is_prefix ? bl.cntP : bl.cntS;
     uint32_t stat = 0;
     for (uint32_t b = blockIdx.x; b < bl.grid; b += gridDim.x) {
         const uint32_t ntask = cnt[b];
-        if (threadIdx.x < 4) s_c[threadIdx.x] = 0;
+        if (threadIdx.x < 5) s_c[threadIdx.x] = 0;
         __syncthreads();
         const uint32_t n_round = (ntask + WAVE - 1) / WAVE * WAVE;
         const uint64_t seg0 = (uint64_t)b * bl.seg;
@@ -483,25 +502,30 @@ __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ 
             uint32_t r = 0;
             int n = 0;
             if (valid) { r = list[seg0 + t]; n = lens[r]; }
-            int jmin, jmax;
-            myers_scan(rows + (uint64_t)r * W, n, dp, jmin, jmax);
-            const bool any = valid && jmax > 0;
+            Clusters cl;
+            myers_scan(rows + (uint64_t)r * W, n, dp, s_eq, cl);
+            const bool any = valid && cl.ncl > 0;
             if (valid && !any) (void)dp_commit(true, r, n, false, 0, dp, spans);
-            const int a = max(0, jmin - (int)dp.m - dp.kerr);
-            const int cls = window_class(jmax - a, (int)dp.m + dp.kerr);
+            const int base = (int)dp.m + dp.kerr;
+            const int a1 = max(0, cl.jmin1 - base), a2 = max(0, cl.jmin2 - base);
+            const int cls = window_class(cl, a1, a2, base);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < 4; ++q) {
                 const bool mine = any && cls == q;
                 const uint32_t iw = wave_append(&s_c[q], mine);
-                if (mine) { bl.listW[q][seg0 + iw] = r; bl.winW[q][seg0 + iw] = (uint32_t)a | ((uint32_t)jmax << 16); }
+                if (mine) {
+                    bl.listW[q][seg0 + iw] = r;
+                    bl.winW[q][seg0 + iw] = (uint32_t)a1 | ((uint32_t)cl.jmax1 << 16);
+                    if (q == 3) bl.winW2[seg0 + iw] = (uint32_t)a2 | ((uint32_t)cl.jmax2 << 16);
+                }
             }
-            const bool toF = any && cls == 3;
-            const uint32_t jf = wave_append(&s_c[3], toF);
+            const bool toF = any && cls == 4;
+            const uint32_t jf = wave_append(&s_c[4], toF);
             if (toF) bl.listF[seg0 + jf] = r;
         }
         __syncthreads();
-        if (threadIdx.x < 3) bl.cntW[threadIdx.x][b] = s_c[threadIdx.x];
-        if (threadIdx.x == 3) bl.cntF[b] = s_c[3];
+        if (threadIdx.x < 4) bl.cntW[threadIdx.x][b] = s_c[threadIdx.x];
+        if (threadIdx.x == 4) bl.cntF[b] = s_c[4];
         stat += ntask;
         __syncthreads();
     }
@@ -512,9 +536,9 @@ __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ 
 // the same DP as dp_align over read columns (a, b] only; column a is the boundary: the true first
 // column when a == 0, otherwise -inf (every cell left of the window is off all accepting paths)
 template <int M>
-__device__ __forceinline__ void dp_window(const uint32_t *__restrict__ row, int W, int n, int a, int b, const DpParams &dp,
-                                          const DpLds &L, int &score, int &len) {
-    int32_t HA[M], EA[M], HB[M], EB[M];
+__device__ __forceinline__ void dp_window_run(int32_t (&HA)[M], int32_t (&EA)[M], int32_t (&HB)[M], int32_t (&EB)[M],
+                                              const uint32_t *__restrict__ row, int W, int a, int b, const DpParams &dp,
+                                              const DpLds &L, int32_t &best_s, int32_t &best_v) {
     dp_init<M>(HA, EA, dp, a == 0);
     // 5 dwords hold the window (phase <= 15 bases + 64 columns = 79 <= 80 bases)
     const int wi = a >> 4;
@@ -525,7 +549,7 @@ __device__ __forceinline__ void dp_window(const uint32_t *__restrict__ row, int 
     uint32_t q4 = wi + 4 < W ? row[wi + 4] : 0u;
     const uint32_t ph = 2u * (uint32_t)(a & 15);
     q0 = funnel(q1, q0, ph); q1 = funnel(q2, q1, ph); q2 = funnel(q3, q2, ph); q3 = funnel(q4, q3, ph); q4 >>= ph;
-    int32_t best_s = INT32_MIN, best_v = 0, hl;
+    int32_t hl;
     const int wlen = b - a;
     int t = 0;
     for (; t + 2 <= wlen; t += 2) {
@@ -541,11 +565,27 @@ __device__ __forceinline__ void dp_window(const uint32_t *__restrict__ row, int 
 #pragma unroll
         for (int i = 0; i < M; ++i) { HA[i] = HB[i]; EA[i] = EB[i]; }
     }
-    if (wlen <= 0) { score = INT32_MIN / 2; len = 0; return; }
-    dp_result<M>(HA, best_s, best_v, b == n, dp, score, len);
 }
 
-template <int M>
+// one window, or two disjoint windows left to right (the cells between them are off all accepting
+// paths, so the second window restarts from a -inf boundary; the last-row best keeps running, the
+// last-column cells count only if the final window ends at the read end)
+template <int M, bool TWO>
+__device__ __forceinline__ void dp_window(const uint32_t *__restrict__ row, int W, int n, int a, int b, int a2, int b2,
+                                          const DpParams &dp, const DpLds &L, int &score, int &len) {
+    int32_t HA[M], EA[M], HB[M], EB[M];
+    int32_t best_s = INT32_MIN, best_v = 0;
+    if (b - a <= 0) { score = INT32_MIN / 2; len = 0; return; }
+    dp_window_run<M>(HA, EA, HB, EB, row, W, a, b, dp, L, best_s, best_v);
+    int lastb = b;
+    if (TWO) {
+        dp_window_run<M>(HA, EA, HB, EB, row, W, a2, b2, dp, L, best_s, best_v);
+        lastb = b2;
+    }
+    dp_result<M>(HA, best_s, best_v, lastb == n, dp, score, len);
+}
+
+template <int M, bool TWO>
 __global__ __launch_bounds__(kBlock) void k_dpw(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
                                                 DpParams dp, short2 *__restrict__ spans, BatchLists bl, int cls) {
     __shared__ FlatList fl;
@@ -558,7 +598,7 @@ __global__ __launch_bounds__(kBlock) void k_dpw(const uint32_t *__restrict__ row
     for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < n_round; t += gridDim.x * kBlock) {
         const bool valid = t < total;
         uint32_t r = 0, seg = 0;
-        int n = 0, wa = 0, wb = 0;
+        int n = 0, wa = 0, wb = 0, wa2 = 0, wb2 = 0;
         if (valid) {
             seg = flat_segment(fl, t);
             const uint64_t at = (uint64_t)seg * bl.seg + (t - fl.pre[seg]);
@@ -567,9 +607,14 @@ __global__ __launch_bounds__(kBlock) void k_dpw(const uint32_t *__restrict__ row
             const uint32_t w = win[at];
             wa = (int)(w & 0xFFFFu);
             wb = (int)(w >> 16);
+            if (TWO) {
+                const uint32_t w2 = bl.winW2[at];
+                wa2 = (int)(w2 & 0xFFFFu);
+                wb2 = (int)(w2 >> 16);
+            }
         }
         int score, len;
-        dp_window<M>(rows + (uint64_t)r * W, W, n, wa, wb, dp, L, score, len);
+        dp_window<M, TWO>(rows + (uint64_t)r * W, W, n, wa, wb, wa2, wb2, dp, L, score, len);
         const bool pushS = dp_commit(valid, r, n, score >= dp.T, len, dp, spans);
         if (dp.is_prefix) push_suffix(bl, seg, r, pushS);
     }
@@ -1231,7 +1276,8 @@ static void launch_dp_m(hipStream_t s, int which, int g, const uint32_t *rows, c
                         short2 *spans, BatchLists bl, const uint32_t *list, const uint32_t *cnt, uint32_t count_stat,
                         uint64_t *counters) {
     if (which == 0) hipLaunchKernelGGL(k_dp<M>, dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, list, cnt, count_stat, counters);
-    else hipLaunchKernelGGL(k_dpw<M>, dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, which - 1);
+    else if (which - 1 < 3) hipLaunchKernelGGL((k_dpw<M, false>), dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, which - 1);
+    else hipLaunchKernelGGL((k_dpw<M, true>), dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, which - 1);
 }
 
 static hipError_t launch_dp_any(hipStream_t s, int which, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
@@ -1261,7 +1307,7 @@ hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t 
 
 hipError_t launch_dp_window(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
                             BatchLists bl) {
-    for (int cls = 0; cls < 3; ++cls) {
+    for (int cls = 0; cls < 4; ++cls) {
         hipError_t e = launch_dp_any(s, 1 + cls, W, rows, lens, dp, spans, bl, nullptr, nullptr, 0u, nullptr);
         if (e != hipSuccess) return e;
     }
