@@ -185,6 +185,16 @@ def main():
         ms_tot, launches, bytes_per_launch = kern[dom]
         avg_ms = ms_tot / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM bytes of the dominant kernel from the PMC passes committed under profiles/ (separate
+        # rocprofv3 --pmc runs of this same workload, gfx950 FETCH_SIZE correction applied there)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")))["kernels"]
+            kname = {"scan": "vf::k_scan<10>", "finish": "vf::k_finish<10>"}.get(dom)
+            if kname and L == 150 and n == 10_000_000:
+                traffic = pmc.get(kname, {}).get("traffic")
+        except Exception:
+            traffic = None
         path_ms = sum(v[0] for v in kern.values()) / steps
         path_gbps = n * b_alg(L) / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0
         out = {
@@ -196,7 +206,7 @@ def main():
                        "reads_per_gpu": n, "read_len": L, "adapter_len": args.adapter_len, "variants": args.variants,
                        "sub_rate": args.sub_rate, "indel_rate": args.indel_rate, "parallelism": f"read-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(bytes_per_launch)},
             "roofline_path": {"bound": "hbm", "achieved": round(path_gbps, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": round(path_gbps / HBM_PEAK_GBPS, 6), "alg_bytes_per_read": b_alg(L),
