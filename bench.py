@@ -198,7 +198,7 @@ def main():
         path_ms = sum(v[0] for v in kern.values()) / steps
         path_gbps = n * b_alg(L) / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0
         out = {
-            "metric": "M reads/sec (150 bp, 20 bp adapters)", "value": round(value, 3), "unit": "M reads/s",
+            "metric": f"M reads/sec ({L} bp, {args.adapter_len} bp adapters)", "value": round(value, 3), "unit": "M reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{n} synthetic {L} bp reads per GPU per step, {args.adapter_len} bp adapters, default "

@@ -73,3 +73,24 @@ def write_fastq_gz(path, reads, members=1, crlf=False):
                 continue
             body = b"".join(b"@r%d" % (m * per + i) + nl + r + nl + b"+" + nl + b"F" * len(r) + nl for i, r in enumerate(chunk))
             f.write(gzip.compress(body, compresslevel=1))
+
+
+def fastq_text(reads, first=0, header_extra=b""):
+    return b"".join(b"@r%d" % (first + i) + header_extra + b"\n" + r + b"\n+\n" + b"F" * len(r) + b"\n" for i, r in enumerate(reads))
+
+
+def write_bgzf(path, text, block=65280):
+    """BGZF (bgzip) container: gzip members of <= 64 KiB each carrying a 'BC' extra field, plus the
+    28-byte empty EOF block"""
+    import struct
+    import zlib
+    out = bytearray()
+    for lo in list(range(0, len(text), block)) + [None]:
+        data = b"" if lo is None else text[lo:lo + block]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = co.compress(data) + co.flush()
+        bsize = 12 + 6 + len(body) + 8 - 1
+        out += b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize)
+        out += body + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(out)

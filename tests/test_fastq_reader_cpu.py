@@ -1,0 +1,126 @@
+"""CPU tests of the gzip FASTQ reader (vfind_amd/csrc/vf_fastq.cpp) through a harness that stubs the
+device submission: parallel member decode must deliver exactly the records of the file, in any
+container shape, for any thread count, and report malformed input."""
+import gzip
+import json
+import os
+import subprocess
+
+import pytest
+
+from tests import synth
+from tests.conftest import ROOT
+
+AD20 = ("GATCGGAAGAGCACACGTCT", "AGATCGGAAGAGCGTCGTGT")
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("h") / "fastq_harness")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "fastq_harness.cpp"),
+                           os.path.join(ROOT, "vfind_amd", "csrc", "vf_fastq.cpp"), "-o", exe, "-lz", "-lpthread"])
+    return exe
+
+
+def _run(exe, path, nt, timeout=120):
+    out = subprocess.run([exe, path, str(nt)], capture_output=True, text=True, timeout=timeout).stdout
+    return json.loads(out.strip().splitlines()[-1])
+
+
+def _expect(reads):
+    s = 0
+    for r in reads:
+        h = 1469598103934665603
+        for b in r:
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        s = (s + h) & 0xFFFFFFFFFFFFFFFF
+    return {"rc": 0, "reads": len(reads), "bases": sum(len(r) for r in reads), "checksum": s, "error": ""}
+
+
+def test_reader_container_shapes_and_thread_counts(harness, tmp_path):
+    reads = synth.make_reads(5, 60000, AD20, L=150, vary_len=True)
+    want = _expect(reads)
+    text = synth.fastq_text(reads)
+    files = {}
+    p = str(tmp_path / "single.gz"); open(p, "wb").write(gzip.compress(text, 1)); files["single"] = p
+    p = str(tmp_path / "bgzf.gz"); synth.write_bgzf(p, text); files["bgzf"] = p
+    p = str(tmp_path / "many.gz"); synth.write_fastq_gz(p, reads, members=61); files["61 members"] = p
+    p = str(tmp_path / "crlf.gz"); synth.write_fastq_gz(p, reads, members=3, crlf=True); files["crlf"] = p
+    p = str(tmp_path / "nonl.gz"); open(p, "wb").write(gzip.compress(text[:-1], 6)); files["no final newline"] = p
+    # stored members keep the text verbatim: gzip magic bytes in header lines show up as false member starts
+    tricky = synth.fastq_text(reads[:30000], header_extra=b" \x1f\x8b\x08\x00 x\x1f\x8b\x08\x04") + synth.fastq_text(reads[30000:], first=30000)
+    p = str(tmp_path / "magic.gz")
+    open(p, "wb").write(gzip.compress(tricky[: len(tricky) // 3], 0) + gzip.compress(tricky[len(tricky) // 3:], 0))
+    files["false magic"] = p
+    for name, path in files.items():
+        for nt in (1, 2, 5, 16):
+            assert _run(harness, path, nt) == want, (name, nt)
+
+
+def _stored_member(payload_len):
+    """a valid gzip member made of stored deflate blocks of 'A's whose bytes hold no newline"""
+    import struct
+    import zlib
+    for extra in range(64):
+        data = b"A" * (payload_len + extra)
+        out = bytearray(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\xff")
+        blocks = [data[i:i + 65535] for i in range(0, len(data), 65535)]
+        for k, blk in enumerate(blocks):
+            out += bytes([1 if k == len(blocks) - 1 else 0]) + struct.pack("<HH", len(blk), len(blk) ^ 0xFFFF) + blk
+        out += struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data))
+        if b"\n" not in out and b"\r" not in out:
+            assert gzip.decompress(bytes(out)) == data
+            return bytes(out)
+    raise AssertionError("no newline-free member found")
+
+
+def test_reader_false_start_that_inflates_for_long_does_not_starve(harness, tmp_path, monkeypatch):
+    """a header line carries a complete, valid gzip member that inflates to more than a speculative
+    task may buffer; with one worker the reader must abandon it and serve the real stream"""
+    monkeypatch.setenv("VFIND_FASTQ_SPEC_CAP", str(1 << 20))
+    reads = synth.make_reads(6, 20000, AD20, L=100)
+    filler_reads = synth.make_reads(7, 60000, AD20, L=100)
+    blob = _stored_member(24 << 20)
+    # Member 1 (stored, so the embedded member sits verbatim in the file) = 5 MB of records, then the
+    # record carrying the embedded member, then more records; member 2 = ordinary records.  Task 0 is
+    # member 1; the speculation for the next task ("first magic at or after the 4 MiB grid line") picks
+    # the embedded member, which inflates far past the cap; the true next task starts at member 2.
+    m1 = synth.fastq_text(filler_reads, first=10**6) + synth.fastq_text(reads[:10], first=0, header_extra=b" " + blob) + synth.fastq_text(reads[10:10000], first=10)
+    m2 = synth.fastq_text(reads[10000:], first=10000)
+    assert len(synth.fastq_text(filler_reads)) > (4 << 20) + 100000
+    p = str(tmp_path / "embedded.gz")
+    open(p, "wb").write(gzip.compress(m1, 0) + gzip.compress(m2, 6))
+    want = _expect(filler_reads + reads)
+    for nt in (1, 2, 6):
+        assert _run(harness, p, nt, timeout=120) == want, nt
+    # the false start really was taken and abandoned (debug trace of the single-worker run)
+    env = dict(os.environ, VFIND_FASTQ_DEBUG="1")
+    err = subprocess.run([harness, p, "1"], capture_output=True, text=True, timeout=120, env=env).stderr
+    assert "abort=1" in err
+
+
+def test_reader_errors(harness, tmp_path):
+    good = synth.fastq_text(synth.make_reads(8, 5000, AD20, L=80))
+    cases = {
+        "garbage": gzip.compress(good) + b"trailing bytes that are not gzip........",
+        "truncated": gzip.compress(good)[:-20],
+        "cutmid": gzip.compress(good * 40, 1)[: 3_000_000],
+        "noat": gzip.compress(b"r\nACGT\n+\nFFFF\n"),
+        "qual": gzip.compress(good + b"@x\nACGT\n+\nFFF\n"),
+        "partial": gzip.compress(good + b"@x\nACGT\n+\n"),
+        "blank": gzip.compress(good[:1000].rsplit(b"@", 1)[0] + b"\n" + good),
+    }
+    for name, data in cases.items():
+        p = str(tmp_path / (name + ".gz"))
+        open(p, "wb").write(data)
+        for nt in (1, 4):
+            r = _run(harness, p, nt)
+            assert r["rc"] == 3 and r["error"], (name, nt, r)
+    p = str(tmp_path / "plain.fq")
+    open(p, "wb").write(good)
+    assert _run(harness, p, 2)["rc"] == 3
+    assert _run(harness, str(tmp_path / "missing.gz"), 2)["rc"] == 2
+    p = str(tmp_path / "empty.gz")
+    open(p, "wb").write(gzip.compress(b""))
+    assert _run(harness, p, 2) == {"rc": 0, "reads": 0, "bases": 0, "checksum": 0, "error": ""}

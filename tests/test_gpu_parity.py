@@ -201,6 +201,34 @@ def test_filter_and_window_edge_cases():
         _check_spans(rd, AD20, accept_prefix_alignment=acc, accept_suffix_alignment=acc)
 
 
+@pytest.mark.parametrize("name,kw", [
+    ("cfg2", dict(seed=0x5EED0002, read_len=150, m=20, sub_rate=0.005, indel_rate=0.0005)),
+    ("cfg4", dict(seed=0x5EED0004, read_len=150, m=20, sub_rate=0.15, indel_rate=0.0)),
+    ("cfg5", dict(seed=0x5EED0005, read_len=300, m=30, sub_rate=0.005, indel_rate=0.0005))])
+def test_baseline_config_shapes_small_scale(name, kw):
+    """BASELINE.json configs[1], [3], [4] at 40 k reads through the bench's own generator: spans and the
+    (sequence,count) table equal the oracle; full sizes are covered by bench.py's parity gate"""
+    from vfind_amd import synth as vsynth
+    ads = vsynth.adapters(kw["seed"], kw["m"])
+    gen = vsynth.Generator(kw["seed"], ads, read_len=kw["read_len"], n_variants=5000, sub_rate=kw["sub_rate"], indel_rate=kw["indel_rate"])
+    data, offs = gen.ascii(0, 40000, 8)
+    with _engine(ads) as e:
+        st, en = e.spans((data, offs))
+        e.submit((data, offs))
+        got = e.finish_dict()
+        stats = e.stats()
+    ost, oen = oracle.spans((data, offs), ads, n_threads=8)
+    assert (st == ost).all() and (en == oen).all()
+    want = oracle.count((data, offs), ads, n_threads=8)
+    assert got == want and len(got) > 100
+    # the packed-row generator output equals host packing of the ASCII output
+    rows, lens = gen.packed(0, 2000, 4)
+    with _engine(ads) as e:
+        e.submit_packed(rows, lens)
+        assert e.finish_dict() == oracle.count((data[:2000 * kw["read_len"]], offs[:2001]), ads)
+    assert stats["dp_prefix"] > 0
+
+
 def test_small_batches_and_slot_reuse():
     reads = synth.make_reads(71, 5000, AD20, L=150, sub=0.02, indel=0.005, dirty=0.05)
     _check_counts(reads, AD20, batch_reads=257, queue_len=3)
@@ -227,6 +255,38 @@ def test_fastq_end_to_end_multimember_gzip(tmp_path):
     seqs = out["sequence"].to_list() if hasattr(out["sequence"], "to_list") else out["sequence"].to_pylist()
     cnts = out["count"].to_list() if hasattr(out["count"], "to_list") else out["count"].to_pylist()
     assert [(s.encode(), c) for s, c in zip(seqs, cnts)] == list(oracle.sorted_table(want))
+
+
+def test_fastq_parallel_member_decode(tmp_path):
+    """the reader inflates gzip members in parallel: BGZF, many small members, members far larger than
+    the task grid, gzip-magic bytes inside the data, and a single member must all give the oracle's table"""
+    import gzip
+    import vfind_amd
+    reads = synth.make_reads(83, 120000, AD20, L=150, sub=0.01, indel=0.002, n_variants=500)
+    want = oracle.count(reads, AD20)
+    text = synth.fastq_text(reads)
+    files = {}
+    p = str(tmp_path / "bgzf.fq.gz"); synth.write_bgzf(p, text); files["bgzf"] = p
+    p = str(tmp_path / "many.fq.gz"); synth.write_fastq_gz(p, reads, members=97); files["97 members"] = p
+    p = str(tmp_path / "single.fq.gz"); open(p, "wb").write(gzip.compress(text, 1)); files["single"] = p
+    # stored (level 0) members keep the text verbatim, so gzip magic bytes in a header line appear in
+    # the compressed file as false member starts
+    tricky = synth.fastq_text(reads[:60000], header_extra=b" \x1f\x8b\x08\x04 x") + synth.fastq_text(reads[60000:], first=60000)
+    p = str(tmp_path / "magic.fq.gz")
+    open(p, "wb").write(gzip.compress(tricky[: len(tricky) // 2], 0) + gzip.compress(tricky[len(tricky) // 2:], 0))
+    files["false magic"] = p
+    for name, path in files.items():
+        assert oracle.count_fastq(path, AD20) == want, name
+        for nt in (1, 4, 16):
+            with vfind_amd.Engine(AD20, n_threads=nt, table_slots=1 << 16) as e:
+                e.run_fastq(path)
+                assert e.finish_dict() == want, (name, nt)
+                assert e.stats()["reads"] == len(reads)
+    # trailing garbage after the last member is an error, as for the reference's MultiGzDecoder
+    p = str(tmp_path / "garbage.fq.gz")
+    open(p, "wb").write(gzip.compress(text[:100000]) + b"this is not gzip")
+    with pytest.raises(vfind_amd.VfindError, match="gzip"):
+        vfind_amd.find_variants(p, AD20)
 
 
 def test_fastq_errors(tmp_path):

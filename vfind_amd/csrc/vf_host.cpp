@@ -7,6 +7,7 @@
 // kernels in vf_kernels.hip; the host only decodes, packs, launches and formats.
 #include "../../include/vfind_hip.h"
 #include "vf_device.h"
+#include "vf_internal.h"
 
 #include <zlib.h>
 
@@ -173,8 +174,6 @@ struct Slot {
     PinBuf<short2> h_spans;
     std::vector<uint32_t> fast_idx, gen_idx;   // original positions (vf_spans_ascii)
 };
-
-struct ReadRef { uint64_t off; uint32_t len; };
 
 }  // namespace
 
@@ -925,165 +924,16 @@ extern "C" int vf_set_profiling(vf_ctx *c, int on) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// gzip FASTQ input (lib.rs:233-234): one inflating reader thread cuts the text into chunks of whole
-// records; n_threads workers frame the records, pack and submit
+// hooks for the FASTQ reader (vf_fastq.cpp)
 // ------------------------------------------------------------------------------------------------
-namespace {
-struct Chunk { std::vector<uint8_t> text; size_t used = 0; };
-
-struct ChunkQueue {
-    std::mutex mu;
-    std::condition_variable cv_put, cv_get;
-    std::deque<std::unique_ptr<Chunk>> q;
-    size_t limit;
-    bool closed = false;
-    explicit ChunkQueue(size_t lim) : limit(lim) {}
-    void put(std::unique_ptr<Chunk> c) {
-        std::unique_lock<std::mutex> lk(mu);
-        cv_put.wait(lk, [&] { return q.size() < limit || closed; });
-        if (closed) return;
-        q.push_back(std::move(c));
-        cv_get.notify_one();
-    }
-    std::unique_ptr<Chunk> get() {
-        std::unique_lock<std::mutex> lk(mu);
-        cv_get.wait(lk, [&] { return !q.empty() || closed; });
-        if (q.empty()) return nullptr;
-        auto c = std::move(q.front());
-        q.pop_front();
-        cv_put.notify_one();
-        return c;
-    }
-    void close() {
-        { std::lock_guard<std::mutex> g(mu); closed = true; }
-        cv_get.notify_all(); cv_put.notify_all();
-    }
-    void abort() {
-        { std::lock_guard<std::mutex> g(mu); closed = true; q.clear(); }
-        cv_get.notify_all(); cv_put.notify_all();
-    }
-};
-
-static void set_async_error(vf_ctx *c, int rc, const std::string &msg) {
+int vf_internal_submit(vf_ctx *c, const uint8_t *base, const ReadRef *reads, uint64_t n) {
+    int rc = submit_reads(c, base, reads, n, nullptr, nullptr);
+    return rc;
+}
+void vf_internal_set_async_error(vf_ctx *c, int rc, const std::string &msg) {
     std::lock_guard<std::mutex> g(c->err_mu);
     if (!c->async_rc) { c->async_rc = rc; c->async_msg = msg; }
 }
-
-// frames strict four-line records in text[0..n); every record must be complete
-static int frame_records(const uint8_t *t, size_t n, std::vector<ReadRef> &out, std::string &err) {
-    size_t p = 0;
-    auto line_end = [&](size_t from) -> size_t {
-        const void *q = memchr(t + from, '\n', n - from);
-        return q ? (size_t)((const uint8_t *)q - t) : n;
-    };
-    while (p < n) {
-        const size_t e1 = line_end(p);
-        if (e1 == p || (e1 == p + 1 && t[p] == '\r')) {            // blank line: only legal as trailing padding
-            size_t k = p;
-            while (k < n && (t[k] == '\n' || t[k] == '\r')) ++k;
-            if (k == n) return VF_OK;
-            err = "malformed FASTQ: blank line inside the file";
-            return VF_EFORMAT;
-        }
-        if (t[p] != '@') { err = "malformed FASTQ: record does not start with '@'"; return VF_EFORMAT; }
-        if (e1 >= n) { err = "malformed FASTQ: truncated record"; return VF_EFORMAT; }
-        const size_t s2 = e1 + 1, e2 = line_end(s2);
-        if (e2 >= n) { err = "malformed FASTQ: truncated record"; return VF_EFORMAT; }
-        size_t sl = e2 - s2;
-        if (sl && t[e2 - 1] == '\r') --sl;
-        const size_t s3 = e2 + 1, e3 = line_end(s3);
-        if (e3 >= n || s3 >= n || t[s3] != '+') { err = "malformed FASTQ: missing '+' separator line"; return VF_EFORMAT; }
-        const size_t s4 = e3 + 1, e4 = line_end(s4);
-        size_t ql = e4 - s4;
-        if (ql && t[e4 - 1] == '\r') --ql;
-        if (ql != sl) { err = "malformed FASTQ: sequence and quality lengths differ"; return VF_EFORMAT; }
-        if (sl > 0xFFFFFFFFull) { err = "read too long"; return VF_EFORMAT; }
-        out.push_back(ReadRef{(uint64_t)s2, (uint32_t)sl});
-        p = e4 < n ? e4 + 1 : n;
-    }
-    return VF_OK;
-}
-}  // namespace
-
-extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
-    if (!c || !path) return fail(VF_EINVAL, "null argument");
-    FILE *fp = fopen(path, "rb");
-    if (!fp) return fail(VF_EIO, std::string(path) + ": " + strerror(errno));
-    unsigned char magic[2] = {0, 0};
-    const size_t got = fread(magic, 1, 2, fp);
-    fclose(fp);
-    if (got < 2 || magic[0] != 0x1f || magic[1] != 0x8b)
-        return fail(VF_EFORMAT, std::string(path) + ": not a gzip file (the reference reads gzip FASTQ only)");
-    gzFile gz = gzopen(path, "rb");
-    if (!gz) return fail(VF_EIO, std::string(path) + ": gzopen failed");
-    gzbuffer(gz, 1 << 20);
-
-    const size_t kChunk = 16u << 20;
-    ChunkQueue queue(std::max<size_t>(2, c->n_threads));
-    std::atomic<bool> stop{false};
-
-    std::thread reader([&] {
-        std::vector<uint8_t> carry;
-        bool eof = false;
-        while (!eof && !stop.load()) {
-            std::unique_ptr<Chunk> ch(new Chunk);
-            ch->text.resize(carry.size() + kChunk);
-            if (!carry.empty()) memcpy(ch->text.data(), carry.data(), carry.size());
-            size_t fill = carry.size();
-            carry.clear();
-            while (fill < ch->text.size()) {
-                const int r = gzread(gz, ch->text.data() + fill, (unsigned)std::min<size_t>(ch->text.size() - fill, 1u << 30));
-                if (r < 0) {
-                    int en = 0; const char *m = gzerror(gz, &en);
-                    set_async_error(c, VF_EFORMAT, std::string("gzip error: ") + (m ? m : "?"));
-                    stop = true; break;
-                }
-                if (r == 0) { eof = true; break; }
-                fill += (size_t)r;
-            }
-            if (stop.load()) break;
-            // keep whole records: count newlines from the chunk start, cut after the last 4th one
-            size_t cut = 0, lines = 0, pos = 0;
-            const uint8_t *t = ch->text.data();
-            while (pos < fill) {
-                const void *q = memchr(t + pos, '\n', fill - pos);
-                if (!q) break;
-                pos = (size_t)((const uint8_t *)q - t) + 1;
-                if (++lines % 4 == 0) cut = pos;
-            }
-            if (eof) cut = fill;      // the last record may lack a trailing newline
-            carry.assign(t + cut, t + fill);
-            ch->used = cut;
-            if (eof) carry.clear();
-            if (ch->used) queue.put(std::move(ch));
-            else if (!eof && carry.size() > (1u << 30)) { set_async_error(c, VF_EFORMAT, "malformed FASTQ: record larger than 1 GiB"); stop = true; }
-        }
-        if (eof) {
-            int en = 0; (void)gzerror(gz, &en);
-            if (en != Z_OK && en != Z_STREAM_END) set_async_error(c, VF_EFORMAT, "gzip error: truncated or corrupt stream");
-        }
-        queue.close();
-    });
-
-    std::vector<std::thread> workers;
-    for (uint32_t w = 0; w < c->n_threads; ++w) {
-        workers.emplace_back([&] {
-            std::vector<ReadRef> refs;
-            for (;;) {
-                std::unique_ptr<Chunk> ch = queue.get();
-                if (!ch) break;
-                if (stop.load()) continue;
-                refs.clear();
-                std::string err;
-                int rc = frame_records(ch->text.data(), ch->used, refs, err);
-                if (rc) { set_async_error(c, rc, err); stop = true; queue.abort(); break; }
-                rc = submit_reads(c, ch->text.data(), refs.data(), refs.size(), nullptr, nullptr);
-                if (rc) { set_async_error(c, rc, g_err); stop = true; queue.abort(); break; }
-            }
-        });
-    }
-    reader.join();
-    for (auto &t : workers) t.join();
-    gzclose(gz);
-    return vf_sync(c);
-}
+uint32_t vf_internal_threads(const vf_ctx *c) { return c->n_threads; }
+int vf_internal_fail(int code, const std::string &msg) { return fail(code, msg); }
+std::string vf_internal_last_error() { return g_err; }
