@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget (core-seconds) of the baseline sample")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--table-slots", type=int, default=0, help="count-table slots (0 = 2x the variant library, power of two)")
     args = ap.parse_args()
 
@@ -61,14 +63,23 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    wire = dev if args.backend == "nccl" else torch.device("cpu")
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if args.backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
 
     n = args.reads
     L = args.read_len
@@ -149,7 +160,7 @@ def main():
     merge_ms = None
     counted_local = st["counted"] // max(args.steps, 1)
     if world > 1:
-        tot = torch.tensor([counted_local], dtype=torch.int64, device=dev)
+        tot = torch.tensor([counted_local], dtype=torch.int64, device=wire)
         dist.all_reduce(tot)
         barrier()
         tm = time.perf_counter()
@@ -161,7 +172,7 @@ def main():
             keys, offs, cnts = eng.finish_arrays()
             if int(cnts.sum()) != int(tot.item()):
                 raise SystemExit("MERGE CHECK FAILED: merged counts do not sum to the per-rank totals")
-        t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t_el = torch.tensor([elapsed], dtype=torch.float64, device=wire)
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
         elapsed = float(t_el.item())
 

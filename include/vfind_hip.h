@@ -125,6 +125,25 @@ const uint64_t *vf_result_key_offsets(const vf_result *r); /* rows+1 offsets    
 const uint64_t *vf_result_counts(const vf_result *r);      /* rows counts (UInt64)     */
 void vf_result_free(vf_result *r);
 
+/* Arrow C Data Interface export of the frame (https://arrow.apache.org/docs/format/CDataInterface.html):
+ * a struct array {sequence: large_utf8, count: uint64} whose buffers the exported array owns from
+ * then on (zero-copy hand-off to polars / pyarrow in place of lib.rs:312-319).  After a successful
+ * export the vf_result is empty and must still be freed with vf_result_free. */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+    const char *format; const char *name; const char *metadata; int64_t flags; int64_t n_children;
+    struct ArrowSchema **children; struct ArrowSchema *dictionary;
+    void (*release)(struct ArrowSchema *); void *private_data;
+};
+struct ArrowArray {
+    int64_t length; int64_t null_count; int64_t offset; int64_t n_buffers; int64_t n_children;
+    const void **buffers; struct ArrowArray **children; struct ArrowArray *dictionary;
+    void (*release)(struct ArrowArray *); void *private_data;
+};
+#endif
+int vf_result_export_arrow(vf_result *r, struct ArrowArray *out_array, struct ArrowSchema *out_schema);
+
 /* Empties the device count table (a new find_variants call on a reused context).  Asynchronous:
  * ordered after every batch already submitted and before everything submitted afterwards. */
 int vf_table_clear(vf_ctx *ctx);

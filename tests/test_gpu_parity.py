@@ -339,3 +339,44 @@ def test_capacity_error_is_loud():
         e.submit(reads)
         with pytest.raises(VfindError, match="table full|arena full"):
             e.finish_dict()
+
+
+def test_arrow_export_frame():
+    """finish() hands the frame over through the Arrow C Data Interface: schema {sequence: large_string,
+    count: uint64}, same rows and order as the plain accessors, buffers stay valid after the context dies"""
+    import pyarrow as pa
+    reads = synth.make_reads(97, 30000, AD20, L=150, n_variants=3000)
+    with _engine(AD20) as e:
+        e.submit(reads)
+        frame = e.finish()
+        plain = list(oracle.sorted_table(e.finish_dict()))
+        e.clear()
+        empty = e.finish()
+    tab = frame if isinstance(frame, pa.Table) else frame.to_arrow()
+    assert tab.column_names == ["sequence", "count"]
+    assert tab.schema.field("count").type == pa.uint64()
+    assert tab.schema.field("sequence").type in (pa.large_string(), pa.string_view(), pa.string())
+    got = list(zip((s.encode() for s in tab["sequence"].to_pylist()), tab["count"].to_pylist()))
+    assert got == plain and len(got) > 500
+    assert (empty.num_rows if isinstance(empty, pa.Table) else empty.height) == 0
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """bench.py's N>1 path (read sharding by rank, barrier/max timing, table export -> all-gather ->
+    device merge, merged-count check) rehearsed with 2 ranks sharing cuda:0 over gloo; on the 8-GPU
+    node the same code runs over RCCL"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--reads", "400000", "--variants", "30000", "--backend", "gloo", "--same-device", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["merge_ms"] is not None and j["parity_gate"] is True

@@ -146,8 +146,24 @@ class Engine:
         return {raw[int(offs[i]):int(offs[i + 1])]: int(cnts[i]) for i in range(len(cnts))}
 
     def finish(self):
-        """the (sequence, count) frame of lib.rs:312-319: polars if importable, else pyarrow"""
-        return _to_frame(*self.finish_arrays())
+        """the (sequence, count) frame of lib.rs:312-319: polars.DataFrame if polars is importable, else
+        a pyarrow.Table; the buffers come straight from the library through the Arrow C Data Interface"""
+        import pyarrow as pa
+
+        res = C.c_void_p()
+        check(self._L.vf_finish(self._ctx, C.byref(res)))
+        try:
+            arr = (C.c_uint64 * 10)()          # struct ArrowArray
+            sch = (C.c_uint64 * 9)()           # struct ArrowSchema
+            check(self._L.vf_result_export_arrow(res, C.addressof(arr), C.addressof(sch)))
+            batch = pa.RecordBatch._import_from_c(C.addressof(arr), C.addressof(sch))
+        finally:
+            self._L.vf_result_free(res)
+        try:
+            import polars as pl
+        except ImportError:
+            return pa.Table.from_batches([batch])
+        return pl.from_arrow(batch)
 
     # ---- multi-GPU exchange ----------------------------------------------------------------------
     def export_size(self) -> int:

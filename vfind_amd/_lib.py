@@ -55,6 +55,7 @@ SYMBOLS = [
     ("vf_result_key_offsets", _P, [_P]),
     ("vf_result_counts", _P, [_P]),
     ("vf_result_free", None, [_P]),
+    ("vf_result_export_arrow", C.c_int, [_P, _P, _P]),
     ("vf_table_clear", C.c_int, [_P]),
     ("vf_table_export_size", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("vf_table_export", C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),

@@ -219,11 +219,6 @@ struct vf_ctx {
     std::string async_msg;
 };
 
-struct vf_result {
-    std::vector<uint8_t> keys;
-    std::vector<uint64_t> offsets;
-    std::vector<uint64_t> counts;
-};
 
 // ------------------------------------------------------------------------------------------------
 // parameter derivation

@@ -3,6 +3,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 struct vf_ctx;
 struct ReadRef { uint64_t off; uint32_t len; };   // a sequence inside a text buffer
@@ -12,3 +13,10 @@ void vf_internal_set_async_error(vf_ctx *c, int rc, const std::string &msg);
 uint32_t vf_internal_threads(const vf_ctx *c);
 int vf_internal_fail(int code, const std::string &msg);      // sets the calling thread's error text
 std::string vf_internal_last_error();
+
+// the (sequence, count) frame handed over the ABI (lib.rs:312-319): rows sorted count desc, sequence asc
+struct vf_result {
+    std::vector<uint8_t> keys;        // concatenated UTF-8 keys
+    std::vector<uint64_t> offsets;    // rows + 1
+    std::vector<uint64_t> counts;     // rows
+};

@@ -26,15 +26,19 @@ def allgather_blobs(send, nbytes: int, group=None) -> List[Tuple[object, int]]:
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    sizes = torch.zeros(world, dtype=torch.int64, device=send.device)
+    # gloo (CPU tests, or a single-GPU rehearsal of the multi-rank path) moves the bytes through
+    # host memory; nccl (= RCCL) gathers device to device over xGMI
+    via_host = dist.get_backend(group) == "gloo" and send.device.type != "cpu"
+    wire = torch.device("cpu") if via_host else send.device
+    sizes = torch.zeros(world, dtype=torch.int64, device=wire)
     sizes[rank] = nbytes
     dist.all_reduce(sizes, group=group)
     sizes_h = [int(x) for x in sizes.cpu().tolist()]
     cap = (max(sizes_h) + 255) // 256 * 256
-    if send.numel() < cap:
-        pad = torch.zeros(cap, dtype=torch.uint8, device=send.device)
-        pad[:nbytes] = send[:nbytes]
-        send = pad
-    recv = torch.empty(world * cap, dtype=torch.uint8, device=send.device)
-    dist.all_gather_into_tensor(recv, send[:cap].contiguous(), group=group)
+    buf = torch.zeros(cap, dtype=torch.uint8, device=wire)
+    buf[:nbytes] = send[:nbytes].to(wire)
+    recv = torch.empty(world * cap, dtype=torch.uint8, device=wire)
+    dist.all_gather_into_tensor(recv, buf, group=group)
+    if via_host:
+        recv = recv.to(send.device)
     return [(recv[r * cap:(r + 1) * cap], sizes_h[r]) for r in range(world)]
