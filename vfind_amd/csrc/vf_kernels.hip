@@ -442,9 +442,10 @@ __device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int
         if (w + 1 < nwords) word_next = row[w + 1];
         const int kmax = min(16, n - 16 * w);
         uint32_t miss = 0;
-        for (int k = 0; k < kmax; ++k) {
-            const uint32_t Eq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_eq) + ((word & 3u) << 2));
-            word >>= 2;
+        auto eq_of = [&](uint32_t base2) {                 // LDS read of the Eq mask of one base
+            return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_eq) + (base2 << 2));
+        };
+        auto column = [&](uint32_t Eq) {
             const uint32_t Xv = Eq | Mv;
             const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
             uint32_t Ph = Mv | ~(Xh | Pv);
@@ -455,6 +456,19 @@ __device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int
             Pv = Mh | ~(Xv | Ph);
             Mv = Ph & Xv;
             miss = (miss << 1) | ((uint32_t)(dp.kerr - sc) >> 31);
+        };
+        // four columns per trip: their Eq masks are read from LDS together, so the dependent chain of
+        // a column waits for LDS once per four columns instead of every column
+        int k = 0;
+        for (; k + 4 <= kmax; k += 4) {
+            const uint32_t e0 = eq_of(word & 3u), e1 = eq_of((word >> 2) & 3u), e2 = eq_of((word >> 4) & 3u), e3 = eq_of((word >> 6) & 3u);
+            word >>= 8;
+            column(e0); column(e1); column(e2); column(e3);
+        }
+        for (; k < kmax; ++k) {
+            const uint32_t e0 = eq_of(word & 3u);
+            word >>= 2;
+            column(e0);
         }
         uint32_t det = ~miss & ((1u << kmax) - 1u);     // bit kmax-1-k <=> column 16w+k+1 detected
         while (det) {
@@ -694,6 +708,24 @@ __device__ __forceinline__ void slot_load(const uint4 *p, uint4 &a, uint4 &b, ui
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p) : "memory");
 }
+// whole-slot write-through store: four 16-byte sc1 stores (8-byte sc1 stores are one fabric write each
+// and cost 2.7x per byte, MI355X_MICROARCH "stores of each flavour")
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void slot_store(uint4 *p, u32x4 a, u32x4 b, u32x4 c, u32x4 d) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\t"
+                 "global_store_dwordx4 %0, %2, off offset:16 sc1\n\t"
+                 "global_store_dwordx4 %0, %3, off offset:32 sc1\n\t"
+                 "global_store_dwordx4 %0, %4, off offset:48 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 :: "v"(p), "v"(a), "v"(b), "v"(c), "v"(d) : "memory");
+}
+__device__ __forceinline__ void slot_store_nowait(uint4 *p, u32x4 a, u32x4 b, u32x4 c, u32x4 d) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\t"
+                 "global_store_dwordx4 %0, %2, off offset:16 sc1\n\t"
+                 "global_store_dwordx4 %0, %3, off offset:32 sc1\n\t"
+                 "global_store_dwordx4 %0, %4, off offset:48 sc1"
+                 :: "v"(p), "v"(a), "v"(b), "v"(c), "v"(d) : "memory");
+}
 __device__ __forceinline__ unsigned long long *slot_count(const Table &t, uint32_t slot) {
     return reinterpret_cast<unsigned long long *>(t.counts) + slot;
 }
@@ -759,6 +791,12 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
     hash_fin(h);
     const bool is_long = nd > (uint32_t)kInlineDwords;
     const uint64_t w0mine = (uint64_t)h.h2 | ((uint64_t)meta << 32) | (is_long ? kW0Long : 0ull);
+    // Letter keys (kind 0) validate themselves: every dword of a written key is non-zero, so a slot can
+    // be claimed READY at once and its key stored without waiting; a reader that meets a zero dword
+    // inside the key's length knows the line is still in flight and looks again.  Packed-DNA keys may
+    // hold zero dwords and keep the claim -> store -> wait -> READY order.
+    const bool selfval = kind == kKindBytes && !is_long;
+    const uint64_t w0claim = selfval ? (w0mine | kW0Ready) : w0mine;
     uint32_t kin[kInlineDwords];
     key.head(nd, kin);
     uint32_t slot = h.h1 & t.slot_mask;
@@ -780,16 +818,23 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
                 slot_load(sp, l0, l1, l2, l3);
                 w0 = (uint64_t)l0.x | ((uint64_t)l0.y << 32);
                 if (w0 == 0ull) {
-                    w0 = atomicCAS(reinterpret_cast<unsigned long long *>(sp), 0ull, (unsigned long long)w0mine);
+                    w0 = atomicCAS(reinterpret_cast<unsigned long long *>(sp), 0ull, (unsigned long long)w0claim);
                     claimed = w0 == 0ull;
                 }
             }
             if (claimed) {
                 unsigned long long *kw = reinterpret_cast<unsigned long long *>(sp) + 1;
-                if (!is_long) {
-#pragma unroll
-                    for (int d = 0; d < kInlineDwords; d += 2) st_agent(kw + d / 2, (unsigned long long)kin[d] | ((unsigned long long)kin[d + 1] << 32));
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (selfval) {
+                    slot_store_nowait(sp, u32x4{(uint32_t)w0claim, (uint32_t)(w0claim >> 32), kin[0], kin[1]}, u32x4{kin[2], kin[3], kin[4], kin[5]},
+                                      u32x4{kin[6], kin[7], kin[8], kin[9]}, u32x4{kin[10], kin[11], kin[12], kin[13]});
+                    atomicAdd(&bt.new_entries, 1u);
+                    atomicAdd(&bt.new_key_dwords, nd);
+                    found = slot;
+                    done = true;
+                } else if (!is_long) {
+                    // the line is ours (w0 claimed, READY clear): rewrite it whole, then publish
+                    slot_store(sp, u32x4{(uint32_t)w0mine, (uint32_t)(w0mine >> 32), kin[0], kin[1]}, u32x4{kin[2], kin[3], kin[4], kin[5]},
+                               u32x4{kin[6], kin[7], kin[8], kin[9]}, u32x4{kin[10], kin[11], kin[12], kin[13]});
                     st_agent(reinterpret_cast<unsigned long long *>(sp), (unsigned long long)(w0mine | kW0Ready));
                     atomicAdd(&bt.new_entries, 1u);
                     atomicAdd(&bt.new_key_dwords, nd);
@@ -829,6 +874,14 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
                         key.each(nd, [&](uint32_t d, uint32_t v) { diff |= ld_agent(&t.arena[off + d]) ^ v; });
                     }
                     if (diff == 0u) { found = slot; done = true; }
+                    else if (selfval) {
+                        // a zero dword inside the key's length = the owner's stores are still in flight
+                        const uint32_t ln[kInlineDwords] = {l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w, l3.x, l3.y, l3.z, l3.w};
+                        bool incomplete = false;
+#pragma unroll
+                        for (int d = 0; d < kInlineDwords; ++d) incomplete = incomplete || ((uint32_t)d < nd && ln[d] == 0u);
+                        if (!incomplete) advance = true;
+                    }
                     else if (!confirmed && !is_long) confirmed = true;      // re-read once now that READY is known
                     else advance = true;
                 }
@@ -903,22 +956,29 @@ __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ 
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const uint64_t n_round = (n_reads + WAVE - 1) / WAVE * WAVE;
-    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n_round; r += stride) {
-        bool ok = false;
-        int start = 0, end = 0;
-        if (r < n_reads) {
-            const short2 sp = spans[r];
-            start = sp.x; end = sp.y;
-            ok = start >= 0 && end >= 0 && start < end;             // lib.rs:288
+    // The kernel is latency bound (span load -> row load -> table probe -> insert are dependent round
+    // trips), so the span and the row of the NEXT iteration are fetched before the current read goes to
+    // the table; rows are fetched unconditionally to keep the two loads independent.
+    short2 sp_next = make_short2(kNone, kNone);
+    uint32_t x_next[W + 2];
+    auto prefetch = [&](uint64_t rr) {
+        if (rr < n_reads) { sp_next = spans[rr]; load_row<W>(rows, rr, x_next); }
+        else {
+            sp_next = make_short2(kNone, kNone);
+#pragma unroll
+            for (int i = 0; i < W + 2; ++i) x_next[i] = 0;
         }
+    };
+    prefetch((uint64_t)blockIdx.x * kBlock + threadIdx.x);
+    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n_round; r += stride) {
+        const int start = sp_next.x, end = sp_next.y;
+        const bool ok = start >= 0 && end >= 0 && start < end;      // lib.rs:288
+        uint32_t x[W + 2];
+#pragma unroll
+        for (int i = 0; i < W + 2; ++i) x[i] = x_next[i];
+        prefetch(r + stride);
         wave_count_lds(&s_stat[0], ok);
         if (!__any(ok)) continue;
-        uint32_t x[W + 2];
-        if (ok) load_row<W>(rows, r, x);
-        else {
-#pragma unroll
-            for (int i = 0; i < W + 2; ++i) x[i] = 0;
-        }
         // shift the row right by `start` bases: word-granular barrel shifter, then bit funnel
         const uint32_t sh = 2u * (uint32_t)start, ws = sh >> 5, bs = sh & 31u;
 #pragma unroll
