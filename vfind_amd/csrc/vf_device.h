@@ -108,7 +108,7 @@ hipError_t launch_scan(hipStream_t s, int W, const uint32_t *rows, const uint16_
                        const ScanParams &sp, short2 *spans, BatchLists bl);
 hipError_t launch_filter(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
                          short2 *spans, BatchLists bl, uint64_t *counters);
-hipError_t launch_dp_window(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
+hipError_t launch_dp_window(hipStream_t s, int cls, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
                             short2 *spans, BatchLists bl);
 hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
                      short2 *spans, BatchLists bl, bool from_filter, uint64_t *counters);

@@ -156,7 +156,26 @@ struct Workspace {               // device scratch of one in-flight batch
     }
 };
 
+// side streams of one in-order lane of work (a batch slot, or the resident path): concurrent DP consumers
+struct Lane {
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
+    int init() {
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return fail(VF_EDEVICE, "hipEventCreate failed");
+        for (int i = 0; i < 4; ++i) {
+            if (hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess) return fail(VF_EDEVICE, "hipStreamCreate failed");
+            if (hipEventCreateWithFlags(&join[i], hipEventDisableTiming) != hipSuccess) return fail(VF_EDEVICE, "hipEventCreate failed");
+        }
+        return VF_OK;
+    }
+    void destroy() {
+        for (int i = 0; i < 4; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (join[i]) (void)hipEventDestroy(join[i]); }
+        if (fork) (void)hipEventDestroy(fork);
+    }
+};
+
 struct Slot {
+    Lane lane;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     uint32_t index = 0;          // chunk-state row of this slot's stream
@@ -203,6 +222,7 @@ struct vf_ctx {
     std::mutex mu;
     std::condition_variable cv;
     hipStream_t main_stream = nullptr;
+    Lane main_lane;
     hipEvent_t clear_event = nullptr;   // recorded on main_stream after each table clear
     Workspace resident;          // for vf_process_device_packed
     DevBuf<uint64_t> exp_refs, exp_counts;
@@ -336,6 +356,7 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     HIP_TRY(hipSetDevice(c->dev));
     HIP_TRY(hipStreamCreateWithFlags(&c->main_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->clear_event, hipEventDisableTiming));
+    if ((rc = c->main_lane.init())) return rc;
 
     // adapters on the device (byte-wise kernel)
     const size_t alen = c->pre.size() + c->suf.size();
@@ -383,6 +404,7 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
         s->index = i;
         HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+        if ((rc = s->lane.init())) return rc;
         c->slots.push_back(std::move(s));
     }
     *out = c.release();
@@ -399,12 +421,14 @@ extern "C" void vf_ctx_destroy(vf_ctx *c) {
         s->h_gbytes.release(); s->h_goffs.release(); s->d_gbytes.release(); s->d_goffs.release();
         s->d_gstart.release(); s->d_gend.release(); s->d_gws.release(); s->h_gstart.release(); s->h_gend.release();
         s->h_spans.release();
+        s->lane.destroy();
         if (s->done) (void)hipEventDestroy(s->done);
         if (s->stream) (void)hipStreamDestroy(s->stream);
     }
     c->resident.release(); c->exp_refs.release(); c->exp_counts.release();
     c->t_slots.release(); c->t_counts.release(); c->t_arena.release(); c->t_counters.release(); c->t_chunks.release();
     c->d_adapters.release();
+    c->main_lane.destroy();
     if (c->clear_event) (void)hipEventDestroy(c->clear_event);
     if (c->main_stream) (void)hipStreamDestroy(c->main_stream);
     delete c;
@@ -445,7 +469,7 @@ struct Timed {
 // ------------------------------------------------------------------------------------------------
 // device path over one packed batch (rows/lens already in HBM)
 // ------------------------------------------------------------------------------------------------
-static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &ws, const uint32_t *d_rows, int W,
+static int run_packed(vf_ctx *c, hipStream_t st, Lane &lane, uint32_t chunk_row, Workspace &ws, const uint32_t *d_rows, int W,
                       const uint16_t *d_lens, uint64_t n, short2 *d_spans, bool count) {
     if (n == 0) return VF_OK;
     if (n > 0xFFFFFFF0ull) return fail(VF_EINVAL, "batch too large (max 2^32-16 reads per submission)");
@@ -467,9 +491,18 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
         const DpParams &dp = role == 0 ? dpP : dpS;
         Timed t(c, st, role == 0 ? K_DPP : K_DPS);
         if (c->filter_on) {
+            // The five consumers of the filter's lists (four window classes + the full-width rest) are
+            // independent; only the first class is big.  They run side by side on the lane's streams so
+            // the small, latency-bound launches hide under the big one instead of queueing behind it.
             HIP_TRY(launch_filter(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters));
-            HIP_TRY(launch_dp_window(st, W, d_rows, d_lens, dp, d_spans, bl));
-            HIP_TRY(launch_dp(st, W, d_rows, d_lens, dp, d_spans, bl, true, c->tab.counters));
+            HIP_TRY(hipEventRecord(lane.fork, st));
+            for (int q = 0; q < 5; ++q) {
+                hipStream_t sq = q == 0 ? st : lane.side[q - 1];
+                if (q) HIP_TRY(hipStreamWaitEvent(sq, lane.fork, 0));
+                if (q < 4) HIP_TRY(launch_dp_window(sq, q, W, d_rows, d_lens, dp, d_spans, bl));
+                else HIP_TRY(launch_dp(sq, W, d_rows, d_lens, dp, d_spans, bl, true, c->tab.counters));
+                if (q) { HIP_TRY(hipEventRecord(lane.join[q - 1], sq)); HIP_TRY(hipStreamWaitEvent(st, lane.join[q - 1], 0)); }
+            }
         } else {
             HIP_TRY(launch_dp(st, W, d_rows, d_lens, dp, d_spans, bl, false, c->tab.counters));
         }
@@ -594,7 +627,7 @@ static int submit_chunk(vf_ctx *c, const uint8_t *base, const ReadRef *reads, ui
         if ((rc = s->ws.ensure(nf))) return rc;
         HIP_TRY(hipMemcpyAsync(s->d_rows.p, s->h_rows.p, (size_t)nf * W * 4, hipMemcpyHostToDevice, s->stream));
         HIP_TRY(hipMemcpyAsync(s->d_lens.p, s->h_lens.p, nf * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
-        if ((rc = run_packed(c, s->stream, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, nf, s->ws.spans.p, !spans_mode))) return rc;
+        if ((rc = run_packed(c, s->stream, s->lane, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, nf, s->ws.spans.p, !spans_mode))) return rc;
     }
     if (ng) {
         if ((rc = run_generic(c, *s, ng, gbytes, gmax, !spans_mode, spans_mode))) return rc;
@@ -688,7 +721,7 @@ extern "C" int vf_submit_packed(vf_ctx *c, const uint32_t *rows, uint32_t W, con
         if ((rc = s->ws.ensure(m))) return rc;
         HIP_TRY(hipMemcpyAsync(s->d_rows.p, s->h_rows.p, (size_t)m * W * 4, hipMemcpyHostToDevice, s->stream));
         HIP_TRY(hipMemcpyAsync(s->d_lens.p, s->h_lens.p, m * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
-        if ((rc = run_packed(c, s->stream, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, m, s->ws.spans.p, true))) return rc;
+        if ((rc = run_packed(c, s->stream, s->lane, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, m, s->ws.spans.p, true))) return rc;
         HIP_TRY(hipEventRecord(s->done, s->stream));
         s->in_flight = true;
         c->n_reads += m;
@@ -704,7 +737,7 @@ extern "C" int vf_process_device_packed(vf_ctx *c, const void *d_rows, uint32_t 
     int rc;
     if ((rc = c->resident.ensure(n))) return rc;
     short2 *spans = d_spans ? (short2 *)d_spans : c->resident.spans.p;
-    if ((rc = run_packed(c, c->main_stream, kChunkRows - 1, c->resident, (const uint32_t *)d_rows, (int)W, (const uint16_t *)d_lens, n, spans, true))) return rc;
+    if ((rc = run_packed(c, c->main_stream, c->main_lane, kChunkRows - 1, c->resident, (const uint32_t *)d_rows, (int)W, (const uint16_t *)d_lens, n, spans, true))) return rc;
     c->n_reads += n;
     return VF_OK;
 }

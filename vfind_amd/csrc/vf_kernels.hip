@@ -1365,13 +1365,10 @@ hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t 
     return launch_dp_any(s, 0, W, rows, lens, dp, spans, bl, list, cnt, from_filter ? 0u : 1u, counters);
 }
 
-hipError_t launch_dp_window(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
-                            BatchLists bl) {
-    for (int cls = 0; cls < 4; ++cls) {
-        hipError_t e = launch_dp_any(s, 1 + cls, W, rows, lens, dp, spans, bl, nullptr, nullptr, 0u, nullptr);
-        if (e != hipSuccess) return e;
-    }
-    return hipSuccess;
+// window class `cls` (0..3) of the filter's output
+hipError_t launch_dp_window(hipStream_t s, int cls, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
+                            short2 *spans, BatchLists bl) {
+    return launch_dp_any(s, 1 + cls, W, rows, lens, dp, spans, bl, nullptr, nullptr, 0u, nullptr);
 }
 
 hipError_t launch_filter(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
