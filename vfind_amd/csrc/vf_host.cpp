@@ -174,6 +174,16 @@ struct Lane {
     }
 };
 
+struct Slot;
+struct ResLane {                 // one of the in-order lanes vf_process_device_packed alternates between
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+    uint32_t chunk_row = 0;
+    Lane lane;
+    Workspace ws;
+};
+
 struct Slot {
     Lane lane;
     hipStream_t stream = nullptr;
@@ -224,7 +234,8 @@ struct vf_ctx {
     hipStream_t main_stream = nullptr;
     Lane main_lane;
     hipEvent_t clear_event = nullptr;   // recorded on main_stream after each table clear
-    Workspace resident;          // for vf_process_device_packed
+    ResLane res[2];              // vf_process_device_packed: batch k+1's scan/DP overlaps batch k's finish
+    uint32_t res_next = 0;
     DevBuf<uint64_t> exp_refs, exp_counts;
     // stats / profiling
     std::atomic<uint64_t> n_reads{0}, n_generic{0};
@@ -357,6 +368,13 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->main_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->clear_event, hipEventDisableTiming));
     if ((rc = c->main_lane.init())) return rc;
+    for (int i = 0; i < 2; ++i) {
+        ResLane &L = c->res[i];
+        HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+        L.chunk_row = 17 + i;
+        if ((rc = L.lane.init())) return rc;
+    }
 
     // adapters on the device (byte-wise kernel)
     const size_t alen = c->pre.size() + c->suf.size();
@@ -392,7 +410,7 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     if ((rc = c->t_arena.ensure(c->arena_dwords))) return rc;
     if ((rc = c->t_counters.ensure(C_NUM))) return rc;
     if ((rc = c->t_chunks.ensure((size_t)kChunkRows * kMaxGrid))) return rc;
-    c->tab.chunk_state = c->t_chunks.p; c->tab.chunk_row = kChunkRows - 1;
+    c->tab.chunk_state = c->t_chunks.p; c->tab.chunk_row = 16;      // the main stream (merge)
     c->tab.slots = c->t_slots.p;
     c->tab.counts = c->t_counts.p;
     c->tab.arena = c->t_arena.p; c->tab.counters = c->t_counters.p;
@@ -425,7 +443,13 @@ extern "C" void vf_ctx_destroy(vf_ctx *c) {
         if (s->done) (void)hipEventDestroy(s->done);
         if (s->stream) (void)hipStreamDestroy(s->stream);
     }
-    c->resident.release(); c->exp_refs.release(); c->exp_counts.release();
+    for (int i = 0; i < 2; ++i) {
+        ResLane &L = c->res[i];
+        L.ws.release(); L.lane.destroy();
+        if (L.done) (void)hipEventDestroy(L.done);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
+    c->exp_refs.release(); c->exp_counts.release();
     c->t_slots.release(); c->t_counts.release(); c->t_arena.release(); c->t_counters.release(); c->t_chunks.release();
     c->d_adapters.release();
     c->main_lane.destroy();
@@ -509,6 +533,8 @@ static int run_packed(vf_ctx *c, hipStream_t st, Lane &lane, uint32_t chunk_row,
     }
     Table tab = c->tab;
     tab.chunk_row = chunk_row;
+    // only the table kernels are ordered after the latest clear; scan and DP may overlap it
+    if (count) HIP_TRY(hipStreamWaitEvent(st, c->clear_event, 0));
     if (count) { Timed t(c, st, K_FIN); HIP_TRY(launch_finish(st, W, d_rows, d_lens, n, d_spans, (c->skip_translation ? 1u : 0u) | c->debug_flags, tab)); }
     return VF_OK;
 }
@@ -535,6 +561,7 @@ static int run_generic(vf_ctx *c, Slot &s, uint64_t ng, uint64_t nbytes, uint32_
     gp.count_mode = count ? 1 : 0;
     Table tab = c->tab;
     tab.chunk_row = s.index;
+    if (count) HIP_TRY(hipStreamWaitEvent(s.stream, c->clear_event, 0));
     { Timed t(c, s.stream, K_GEN); HIP_TRY(launch_generic(s.stream, s.d_gbytes.p, s.d_goffs.p, ng, gp, ds, de, s.d_gws.p, threads, rows, tab)); }
     return VF_OK;
 }
@@ -574,7 +601,6 @@ static int submit_chunk(vf_ctx *c, const uint8_t *base, const ReadRef *reads, ui
     struct Rel { vf_ctx *c; Slot *s; ~Rel() { release_slot(c, s); } } rel{c, s};
     int rc;
     if ((rc = wait_slot(s))) return rc;
-    HIP_TRY(hipStreamWaitEvent(s->stream, c->clear_event, 0));
 
     // geometry of the fast part
     uint32_t max_fast = 0;
@@ -711,7 +737,6 @@ extern "C" int vf_submit_packed(vf_ctx *c, const uint32_t *rows, uint32_t W, con
         struct Rel { vf_ctx *c; Slot *s; ~Rel() { release_slot(c, s); } } rel{c, s};
         int rc;
         if ((rc = wait_slot(s))) return rc;
-        HIP_TRY(hipStreamWaitEvent(s->stream, c->clear_event, 0));
         if ((rc = s->h_rows.ensure((size_t)m * W))) return rc;
         if ((rc = s->h_lens.ensure(m))) return rc;
         memcpy(s->h_rows.p, rows + lo * W, (size_t)m * W * 4);
@@ -735,9 +760,12 @@ extern "C" int vf_process_device_packed(vf_ctx *c, const void *d_rows, uint32_t 
     if (W != 10 && W != 20 && W != 40) return fail(VF_EINVAL, "row_dwords must be 10, 20 or 40");
     HIP_TRY(hipSetDevice(c->dev));
     int rc;
-    if ((rc = c->resident.ensure(n))) return rc;
-    short2 *spans = d_spans ? (short2 *)d_spans : c->resident.spans.p;
-    if ((rc = run_packed(c, c->main_stream, c->main_lane, kChunkRows - 1, c->resident, (const uint32_t *)d_rows, (int)W, (const uint16_t *)d_lens, n, spans, true))) return rc;
+    ResLane &L = c->res[c->res_next++ & 1u];
+    if ((rc = L.ws.ensure(n))) return rc;
+    short2 *spans = d_spans ? (short2 *)d_spans : L.ws.spans.p;
+    if ((rc = run_packed(c, L.stream, L.lane, L.chunk_row, L.ws, (const uint32_t *)d_rows, (int)W, (const uint16_t *)d_lens, n, spans, true))) return rc;
+    HIP_TRY(hipEventRecord(L.done, L.stream));
+    L.in_flight = true;
     c->n_reads += n;
     return VF_OK;
 }
@@ -764,6 +792,10 @@ extern "C" int vf_sync(vf_ctx *c) {
         HIP_TRY(hipStreamSynchronize(s->stream));
         s->in_flight = false;
     }
+    for (auto &L : c->res) {
+        HIP_TRY(hipStreamSynchronize(L.stream));
+        L.in_flight = false;
+    }
     HIP_TRY(hipStreamSynchronize(c->main_stream));
     resolve_events(c);
     return check_device_errors(c, nullptr);
@@ -779,6 +811,8 @@ extern "C" int vf_table_clear(vf_ctx *c) {
     HIP_TRY(hipSetDevice(c->dev));
     for (auto &s : c->slots)
         if (s->in_flight) HIP_TRY(hipStreamWaitEvent(c->main_stream, s->done, 0));
+    for (auto &L : c->res)
+        if (L.in_flight) HIP_TRY(hipStreamWaitEvent(c->main_stream, L.done, 0));
     return table_clear_locked(c);
 }
 
