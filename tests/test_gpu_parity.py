@@ -332,6 +332,20 @@ def test_table_export_merge_and_clear():
         assert e1.finish_dict() == oracle.count(b, AD20)
 
 
+def test_table_grows_between_batches():
+    """a table that fills up is quadrupled and re-hashed on the device between batches"""
+    from vfind_amd import Engine
+    reads = synth.make_reads(96, 60000, AD20, L=150, n_variants=20000, sub=0.002, indel=0.0)
+    for kw in (dict(), dict(skip_translation=True)):
+        with Engine(AD20, table_slots=1 << 10, arena_bytes=1 << 22, batch_reads=400, queue_len=3, **kw) as e:
+            for lo in range(0, len(reads), 5000):
+                e.submit(reads[lo:lo + 5000])
+            got = e.finish_dict()
+            assert e.stats()["table_entries"] == len(got)
+        assert got == oracle.count(reads, AD20, **kw)
+        assert len(got) > 5000
+
+
 def test_capacity_error_is_loud():
     from vfind_amd import Engine, VfindError
     reads = synth.make_reads(95, 4000, AD20, L=150, n_variants=2000)

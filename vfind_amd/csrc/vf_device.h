@@ -118,6 +118,7 @@ hipError_t launch_generic(hipStream_t s, const uint8_t *bytes, const uint64_t *o
                           const GenericParams &gp, int32_t *starts, int32_t *ends, int32_t *ws,
                           uint64_t ws_stride, uint32_t ws_rows, Table t);
 hipError_t launch_export(hipStream_t s, Table t, uint64_t *out_refs, uint64_t *out_counts, uint32_t *out_arena);
+hipError_t launch_rehash(hipStream_t s, Table from, Table to);
 hipError_t launch_merge(hipStream_t s, Table t, const uint64_t *refs, const uint64_t *counts,
                         const uint32_t *arena, uint64_t n);
 

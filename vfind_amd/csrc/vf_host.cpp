@@ -22,6 +22,7 @@
 #include <deque>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -176,6 +177,7 @@ struct Lane {
 
 struct Slot;
 struct ResLane {                 // one of the in-order lanes vf_process_device_packed alternates between
+    PinBuf<uint64_t> h_entries;  // table entry count as of this lane's latest finished batch
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     bool in_flight = false;
@@ -186,6 +188,7 @@ struct ResLane {                 // one of the in-order lanes vf_process_device_
 
 struct Slot {
     Lane lane;
+    PinBuf<uint64_t> h_entries;  // table entry count as of this slot's latest finished batch
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     uint32_t index = 0;          // chunk-state row of this slot's stream
@@ -245,6 +248,8 @@ struct vf_ctx {
     double ms[K_KINDS] = {0, 0, 0, 0, 0};
     uint64_t launches[K_KINDS] = {0, 0, 0, 0, 0};
     // async error from worker threads
+    // table growth: submitters hold it shared while they enqueue, table_grow exclusively
+    std::shared_mutex table_mu;
     std::mutex err_mu;
     int async_rc = 0;
     std::string async_msg;
@@ -373,6 +378,8 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
         HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
         L.chunk_row = 17 + i;
+        if ((rc = L.h_entries.ensure(1))) return rc;
+        *L.h_entries.p = 0;
         if ((rc = L.lane.init())) return rc;
     }
 
@@ -423,6 +430,8 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
         HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
         if ((rc = s->lane.init())) return rc;
+        if ((rc = s->h_entries.ensure(1))) return rc;
+        *s->h_entries.p = 0;
         c->slots.push_back(std::move(s));
     }
     *out = c.release();
@@ -439,13 +448,13 @@ extern "C" void vf_ctx_destroy(vf_ctx *c) {
         s->h_gbytes.release(); s->h_goffs.release(); s->d_gbytes.release(); s->d_goffs.release();
         s->d_gstart.release(); s->d_gend.release(); s->d_gws.release(); s->h_gstart.release(); s->h_gend.release();
         s->h_spans.release();
-        s->lane.destroy();
+        s->lane.destroy(); s->h_entries.release();
         if (s->done) (void)hipEventDestroy(s->done);
         if (s->stream) (void)hipStreamDestroy(s->stream);
     }
     for (int i = 0; i < 2; ++i) {
         ResLane &L = c->res[i];
-        L.ws.release(); L.lane.destroy();
+        L.ws.release(); L.lane.destroy(); L.h_entries.release();
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
@@ -491,10 +500,52 @@ struct Timed {
 };
 
 // ------------------------------------------------------------------------------------------------
+// table growth: when more than half the slots hold keys, quadruple the table and re-insert on the device
+// ------------------------------------------------------------------------------------------------
+static int sync_all_streams(vf_ctx *c) {
+    for (auto &s : c->slots) HIP_TRY(hipStreamSynchronize(s->stream));
+    for (auto &L : c->res) HIP_TRY(hipStreamSynchronize(L.stream));
+    HIP_TRY(hipStreamSynchronize(c->main_stream));
+    return VF_OK;
+}
+
+static int table_grow_if_needed(vf_ctx *c, uint64_t entries_hint) {
+    if (entries_hint * 2 <= c->table_slots) return VF_OK;
+    std::unique_lock<std::shared_mutex> lk(c->table_mu);          // no submitter is enqueueing now
+    int rc;
+    if ((rc = sync_all_streams(c))) return rc;
+    uint64_t h[C_NUM];
+    HIP_TRY(hipMemcpy(h, c->t_counters.p, sizeof(h), hipMemcpyDeviceToHost));
+    while (h[C_ENTRIES] * 2 > c->table_slots) {
+        const uint64_t new_slots = c->table_slots * 4;
+        if (new_slots > (1ull << 32)) return fail(VF_ECAPACITY, "device count table cannot grow beyond 2^32 slots");
+        DevBuf<uint4> n_slots; DevBuf<uint64_t> n_counts;
+        if ((rc = n_slots.ensure(new_slots * 4))) return rc;
+        if ((rc = n_counts.ensure(new_slots))) { n_slots.release(); return rc; }
+        HIP_TRY(hipMemsetAsync(n_slots.p, 0, new_slots * 64, c->main_stream));
+        HIP_TRY(hipMemsetAsync(n_counts.p, 0, new_slots * sizeof(uint64_t), c->main_stream));
+        HIP_TRY(hipMemsetAsync(c->t_counters.p + C_ENTRIES, 0, sizeof(uint64_t), c->main_stream));     // recounted by the re-insert
+        HIP_TRY(hipMemsetAsync(c->t_counters.p + C_KEY_DWORDS, 0, sizeof(uint64_t), c->main_stream));
+        Table to = c->tab;
+        to.slots = n_slots.p; to.counts = n_counts.p; to.slot_mask = (uint32_t)(new_slots - 1);
+        HIP_TRY(launch_rehash(c->main_stream, c->tab, to));
+        HIP_TRY(hipStreamSynchronize(c->main_stream));
+        c->t_slots.release(); c->t_counts.release();
+        c->t_slots = n_slots; c->t_counts = n_counts;
+        c->table_slots = new_slots;
+        c->tab = to;
+        HIP_TRY(hipMemcpy(h, c->t_counters.p, sizeof(h), hipMemcpyDeviceToHost));
+    }
+    for (auto &s : c->slots) if (s->h_entries.p) *s->h_entries.p = h[C_ENTRIES];
+    for (auto &L : c->res) if (L.h_entries.p) *L.h_entries.p = h[C_ENTRIES];
+    return VF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // device path over one packed batch (rows/lens already in HBM)
 // ------------------------------------------------------------------------------------------------
 static int run_packed(vf_ctx *c, hipStream_t st, Lane &lane, uint32_t chunk_row, Workspace &ws, const uint32_t *d_rows, int W,
-                      const uint16_t *d_lens, uint64_t n, short2 *d_spans, bool count) {
+                      const uint16_t *d_lens, uint64_t n, short2 *d_spans, bool count, uint64_t *h_entries) {
     if (n == 0) return VF_OK;
     if (n > 0xFFFFFFF0ull) return fail(VF_EINVAL, "batch too large (max 2^32-16 reads per submission)");
     BatchLists bl{};
@@ -536,6 +587,8 @@ static int run_packed(vf_ctx *c, hipStream_t st, Lane &lane, uint32_t chunk_row,
     // only the table kernels are ordered after the latest clear; scan and DP may overlap it
     if (count) HIP_TRY(hipStreamWaitEvent(st, c->clear_event, 0));
     if (count) { Timed t(c, st, K_FIN); HIP_TRY(launch_finish(st, W, d_rows, d_lens, n, d_spans, (c->skip_translation ? 1u : 0u) | c->debug_flags, tab)); }
+    // the entry count rides back with the batch: the host grows the table between batches when it fills
+    if (count && h_entries) HIP_TRY(hipMemcpyAsync(h_entries, c->t_counters.p + C_ENTRIES, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     return VF_OK;
 }
 
@@ -563,6 +616,7 @@ static int run_generic(vf_ctx *c, Slot &s, uint64_t ng, uint64_t nbytes, uint32_
     tab.chunk_row = s.index;
     if (count) HIP_TRY(hipStreamWaitEvent(s.stream, c->clear_event, 0));
     { Timed t(c, s.stream, K_GEN); HIP_TRY(launch_generic(s.stream, s.d_gbytes.p, s.d_goffs.p, ng, gp, ds, de, s.d_gws.p, threads, rows, tab)); }
+    if (count && s.h_entries.p) HIP_TRY(hipMemcpyAsync(s.h_entries.p, c->t_counters.p + C_ENTRIES, sizeof(uint64_t), hipMemcpyDeviceToHost, s.stream));
     return VF_OK;
 }
 
@@ -601,6 +655,8 @@ static int submit_chunk(vf_ctx *c, const uint8_t *base, const ReadRef *reads, ui
     struct Rel { vf_ctx *c; Slot *s; ~Rel() { release_slot(c, s); } } rel{c, s};
     int rc;
     if ((rc = wait_slot(s))) return rc;
+    if ((rc = table_grow_if_needed(c, *s->h_entries.p))) return rc;
+    std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
 
     // geometry of the fast part
     uint32_t max_fast = 0;
@@ -653,7 +709,7 @@ static int submit_chunk(vf_ctx *c, const uint8_t *base, const ReadRef *reads, ui
         if ((rc = s->ws.ensure(nf))) return rc;
         HIP_TRY(hipMemcpyAsync(s->d_rows.p, s->h_rows.p, (size_t)nf * W * 4, hipMemcpyHostToDevice, s->stream));
         HIP_TRY(hipMemcpyAsync(s->d_lens.p, s->h_lens.p, nf * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
-        if ((rc = run_packed(c, s->stream, s->lane, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, nf, s->ws.spans.p, !spans_mode))) return rc;
+        if ((rc = run_packed(c, s->stream, s->lane, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, nf, s->ws.spans.p, !spans_mode, s->h_entries.p))) return rc;
     }
     if (ng) {
         if ((rc = run_generic(c, *s, ng, gbytes, gmax, !spans_mode, spans_mode))) return rc;
@@ -737,6 +793,8 @@ extern "C" int vf_submit_packed(vf_ctx *c, const uint32_t *rows, uint32_t W, con
         struct Rel { vf_ctx *c; Slot *s; ~Rel() { release_slot(c, s); } } rel{c, s};
         int rc;
         if ((rc = wait_slot(s))) return rc;
+        if ((rc = table_grow_if_needed(c, *s->h_entries.p))) return rc;
+        std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
         if ((rc = s->h_rows.ensure((size_t)m * W))) return rc;
         if ((rc = s->h_lens.ensure(m))) return rc;
         memcpy(s->h_rows.p, rows + lo * W, (size_t)m * W * 4);
@@ -746,7 +804,7 @@ extern "C" int vf_submit_packed(vf_ctx *c, const uint32_t *rows, uint32_t W, con
         if ((rc = s->ws.ensure(m))) return rc;
         HIP_TRY(hipMemcpyAsync(s->d_rows.p, s->h_rows.p, (size_t)m * W * 4, hipMemcpyHostToDevice, s->stream));
         HIP_TRY(hipMemcpyAsync(s->d_lens.p, s->h_lens.p, m * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
-        if ((rc = run_packed(c, s->stream, s->lane, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, m, s->ws.spans.p, true))) return rc;
+        if ((rc = run_packed(c, s->stream, s->lane, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, m, s->ws.spans.p, true, s->h_entries.p))) return rc;
         HIP_TRY(hipEventRecord(s->done, s->stream));
         s->in_flight = true;
         c->n_reads += m;
@@ -761,9 +819,13 @@ extern "C" int vf_process_device_packed(vf_ctx *c, const void *d_rows, uint32_t 
     HIP_TRY(hipSetDevice(c->dev));
     int rc;
     ResLane &L = c->res[c->res_next++ & 1u];
+    if (L.in_flight && hipEventQuery(L.done) == hipSuccess) {           // lane idle: its entry count is current
+        if ((rc = table_grow_if_needed(c, *L.h_entries.p))) return rc;
+    }
+    std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
     if ((rc = L.ws.ensure(n))) return rc;
     short2 *spans = d_spans ? (short2 *)d_spans : L.ws.spans.p;
-    if ((rc = run_packed(c, L.stream, L.lane, L.chunk_row, L.ws, (const uint32_t *)d_rows, (int)W, (const uint16_t *)d_lens, n, spans, true))) return rc;
+    if ((rc = run_packed(c, L.stream, L.lane, L.chunk_row, L.ws, (const uint32_t *)d_rows, (int)W, (const uint16_t *)d_lens, n, spans, true, L.h_entries.p))) return rc;
     HIP_TRY(hipEventRecord(L.done, L.stream));
     L.in_flight = true;
     c->n_reads += n;
@@ -813,6 +875,7 @@ extern "C" int vf_table_clear(vf_ctx *c) {
         if (s->in_flight) HIP_TRY(hipStreamWaitEvent(c->main_stream, s->done, 0));
     for (auto &L : c->res)
         if (L.in_flight) HIP_TRY(hipStreamWaitEvent(c->main_stream, L.done, 0));
+    std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
     return table_clear_locked(c);
 }
 

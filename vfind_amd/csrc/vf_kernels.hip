@@ -1282,6 +1282,36 @@ __global__ __launch_bounds__(kBlock) void k_merge(Table t, const uint64_t *__res
     block_table_end(bt, t);
 }
 
+// every entry of `from` re-inserted into `to` (table growth); both share arena, counters and chunks
+__global__ __launch_bounds__(kBlock) void k_rehash(Table from, Table to) {
+    __shared__ BlockTable bt;
+    block_table_begin(bt, to);
+    __syncthreads();
+    const uint64_t nslots = (uint64_t)from.slot_mask + 1;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t s0 = (uint64_t)blockIdx.x * kBlock; s0 < nslots; s0 += stride) {
+        const uint64_t s = s0 + threadIdx.x;
+        bool live = false;
+        uint64_t w0 = 0, cnt = 0, off = 0;
+        const uint32_t *kp = from.arena;
+        if (s < nslots) {
+            const uint4 *sp = from.slots + s * 4;
+            const uint4 l0 = sp[0];
+            w0 = (uint64_t)l0.x | ((uint64_t)l0.y << 32);
+            live = (w0 & kW0Ready) && !(w0 & kW0Ovf);
+            if (live) {
+                cnt = from.counts[s];
+                off = (uint64_t)l0.z | ((uint64_t)l0.w << 32);
+                kp = (w0 & kW0Long) ? from.arena + off : reinterpret_cast<const uint32_t *>(sp) + 2;
+            }
+        }
+        const uint32_t meta = (uint32_t)(w0 >> 32) & 0x3FFFFu;
+        table_add(to, bt, MemKey{kp, 1ull}, meta >> 16, meta & 0xFFFFu, cnt, live);
+    }
+    __syncthreads();
+    block_table_end(bt, to);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -1416,6 +1446,12 @@ hipError_t launch_merge(hipStream_t s, Table t, const uint64_t *refs, const uint
     if (n == 0) return hipSuccess;
     const int g = grid_for(n, 8);
     hipLaunchKernelGGL(k_merge, dim3(g), dim3(kBlock), 0, s, t, refs, counts, arena, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_rehash(hipStream_t s, Table from, Table to) {
+    const int g = grid_for((uint64_t)from.slot_mask + 1, 8);
+    hipLaunchKernelGGL(k_rehash, dim3(g), dim3(kBlock), 0, s, from, to);
     return hipGetLastError();
 }
 
