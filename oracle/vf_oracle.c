@@ -92,14 +92,13 @@ static inline int POLICY_end_replaces(int cand, int best) { return cand > best; 
  * open + (k-1)*ext; returns score and the alignment-column count of the chosen optimal path.
  * end_q/end_db are 1-based coordinates of the chosen end cell (for tests).  n==0 or m==0 gives
  * score VFO_NEG (the reference would fail inside parasail; callers treat it as "no match"). */
-void vfo_sg_stats(const uint8_t *q, int32_t m, const uint8_t *db, int32_t n, int32_t match,
-                  int32_t mismatch, int32_t open, int32_t ext, int32_t *score, int32_t *length,
-                  int32_t *end_q, int32_t *end_db) {
+/* workspace-taking form used by the batch workers (no allocation per read); ws holds 5*(m+1) ints */
+static void vfo_sg_stats_ws(const uint8_t *q, int32_t m, const uint8_t *db, int32_t n, int32_t match,
+                            int32_t mismatch, int32_t open, int32_t ext, int32_t *score, int32_t *length,
+                            int32_t *end_q, int32_t *end_db, int *ws) {
     *score = VFO_NEG; *length = 0; *end_q = 0; *end_db = 0;
     if (m <= 0 || n <= 0) return;
-    int *H = (int *)malloc(sizeof(int) * 4 * (size_t)(m + 1));
-    int *HL = H + (m + 1), *E = HL + (m + 1), *EL = E + (m + 1);
-    int *qc = (int *)malloc(sizeof(int) * (size_t)m);
+    int *H = ws, *HL = H + (m + 1), *E = HL + (m + 1), *EL = E + (m + 1), *qc = EL + (m + 1);
     for (int i = 0; i < m; ++i) qc[i] = vfo_code(q[i]);
     for (int i = 0; i <= m; ++i) { H[i] = 0; HL[i] = 0; E[i] = VFO_NEG; EL[i] = 0; }
     int best = VFO_NEG, bestL = 0, bq = 0, bd = 0;
@@ -130,7 +129,14 @@ void vfo_sg_stats(const uint8_t *q, int32_t m, const uint8_t *db, int32_t n, int
     for (int i = 1; i < m; ++i)
         if (POLICY_end_replaces(H[i], best)) { best = H[i]; bestL = HL[i]; bq = i; bd = n; }
     *score = best; *length = bestL; *end_q = bq; *end_db = bd;
-    free(qc); free(H);
+}
+
+void vfo_sg_stats(const uint8_t *q, int32_t m, const uint8_t *db, int32_t n, int32_t match,
+                  int32_t mismatch, int32_t open, int32_t ext, int32_t *score, int32_t *length,
+                  int32_t *end_q, int32_t *end_db) {
+    int *ws = (int *)malloc(sizeof(int) * 5 * (size_t)((m > 0 ? m : 0) + 1));
+    vfo_sg_stats_ws(q, m, db, n, match, mismatch, open, ext, score, length, end_q, end_db, ws);
+    free(ws);
 }
 
 /* -------------------------------------------------- thresholds (lib.rs:100-110, 260-261) */
@@ -146,14 +152,15 @@ int vfo_threshold(double accept, int32_t match, int32_t m, int32_t *skip, int64_
 
 /* ------------------------------------------------- find_adapter_match (lib.rs:141-166) */
 /* returns the cut coordinate or -1 (None). */
-int64_t vfo_find_adapter_match(const uint8_t *seq, int64_t n, const uint8_t *ad, int32_t m,
-                               int32_t skip_align, int64_t T, int32_t match, int32_t mismatch,
-                               int32_t open, int32_t ext, int32_t is_prefix) {
+static int64_t vfo_find_adapter_match_ws(const uint8_t *seq, int64_t n, const uint8_t *ad, int32_t m,
+                                         int32_t skip_align, int64_t T, int32_t match, int32_t mismatch,
+                                         int32_t open, int32_t ext, int32_t is_prefix, int *ws) {
     int64_t k = vfo_find_exact(seq, n, ad, m);
     if (k >= 0) return is_prefix ? k + m : k;
     if (skip_align) return -1;
     int32_t score, len, eq, ed;
-    vfo_sg_stats(ad, m, seq, (int32_t)n, match, mismatch, open, ext, &score, &len, &eq, &ed);
+    if (ws) vfo_sg_stats_ws(ad, m, seq, (int32_t)n, match, mismatch, open, ext, &score, &len, &eq, &ed, ws);
+    else vfo_sg_stats(ad, m, seq, (int32_t)n, match, mismatch, open, ext, &score, &len, &eq, &ed);
     if (score == VFO_NEG) return -1;
     if ((int64_t)score >= T) {
         if (is_prefix) return len;
@@ -161,6 +168,11 @@ int64_t vfo_find_adapter_match(const uint8_t *seq, int64_t n, const uint8_t *ad,
         return n - len;
     }
     return -1;
+}
+int64_t vfo_find_adapter_match(const uint8_t *seq, int64_t n, const uint8_t *ad, int32_t m,
+                               int32_t skip_align, int64_t T, int32_t match, int32_t mismatch,
+                               int32_t open, int32_t ext, int32_t is_prefix) {
+    return vfo_find_adapter_match_ws(seq, n, ad, m, skip_align, T, match, mismatch, open, ext, is_prefix, NULL);
 }
 
 /* -------------------------------------------------------- translate (lib.rs:16-44,52-95) */
@@ -278,17 +290,17 @@ static int vfo_derive(const vfo_params *p, vfo_derived *d) {
 }
 
 static void vfo_read_span(const vfo_params *p, const vfo_derived *d, const uint8_t *seq, int64_t n,
-                          int64_t *start, int64_t *end) {
-    *start = vfo_find_adapter_match(seq, n, p->prefix, p->prefix_len, d->skip_p, d->Tp, p->match,
-                                    p->mismatch, p->gap_open, p->gap_extend, 1);
-    *end = vfo_find_adapter_match(seq, n, p->suffix, p->suffix_len, d->skip_s, d->Ts, p->match,
-                                  p->mismatch, p->gap_open, p->gap_extend, 0);
+                          int64_t *start, int64_t *end, int *ws) {
+    *start = vfo_find_adapter_match_ws(seq, n, p->prefix, p->prefix_len, d->skip_p, d->Tp, p->match,
+                                       p->mismatch, p->gap_open, p->gap_extend, 1, ws);
+    *end = vfo_find_adapter_match_ws(seq, n, p->suffix, p->suffix_len, d->skip_s, d->Ts, p->match,
+                                     p->mismatch, p->gap_open, p->gap_extend, 0, ws);
 }
 
 static void vfo_read_count(const vfo_params *p, const vfo_derived *d, const uint8_t *seq, int64_t n,
-                           vfo_table *t, uint8_t *scratch) {
+                           vfo_table *t, uint8_t *scratch, int *ws) {
     int64_t s, e;
-    vfo_read_span(p, d, seq, n, &s, &e);
+    vfo_read_span(p, d, seq, n, &s, &e, ws);
     if (s < 0 || e < 0 || !(s < e)) return;                       /* :288 */
     if (p->skip_translation) {
         if (vfo_valid_utf8(seq + s, e - s)) vfo_table_add(t, seq + s, e - s, 1);   /* :295-296 */
@@ -307,15 +319,18 @@ typedef struct {
 static void *vfo_worker(void *arg) {
     vfo_job *j = (vfo_job *)arg;
     uint8_t *scratch = NULL; int64_t scap = 0;
+    int mmax = j->p->prefix_len > j->p->suffix_len ? j->p->prefix_len : j->p->suffix_len;
+    int *ws = (int *)malloc(sizeof(int) * 5 * (size_t)(mmax + 1));
     for (int64_t r = j->lo; r < j->hi; ++r) {
         const uint8_t *seq = j->bytes + j->offs[r]; int64_t n = (int64_t)(j->offs[r + 1] - j->offs[r]);
-        if (j->starts) vfo_read_span(j->p, j->d, seq, n, &j->starts[r], &j->ends[r]);
+        if (j->starts) vfo_read_span(j->p, j->d, seq, n, &j->starts[r], &j->ends[r], ws);
         if (j->t) {
             if (n / 3 + 1 > scap) { scap = n / 3 + 64; scratch = (uint8_t *)realloc(scratch, (size_t)scap); }
-            vfo_read_count(j->p, j->d, seq, n, j->t, scratch);
+            vfo_read_count(j->p, j->d, seq, n, j->t, scratch, ws);
         }
     }
     free(scratch);
+    free(ws);
     return NULL;
 }
 
