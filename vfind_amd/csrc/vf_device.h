@@ -80,7 +80,7 @@ enum Counter : int {        // uint64 counters[] in device memory
 };
 constexpr int kTableCounters = 4;       // C_ARENA_TOP..C_KEY_DWORDS are reset with the table
 
-constexpr uint32_t kChunkRows = 19;     // chunk-state rows: 16 batch streams, the main stream, 2 resident lanes
+constexpr uint32_t kChunkRows = 21;     // chunk-state rows: 16 batch streams, the main stream, 4 resident lanes
 
 struct Table {
     unsigned long long *chunk_state;  // [kChunkRows][kMaxGrid] workgroup arena chunks (see arena_alloc)

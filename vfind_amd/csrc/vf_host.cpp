@@ -159,18 +159,19 @@ struct Workspace {               // device scratch of one in-flight batch
 
 // side streams of one in-order lane of work (a batch slot, or the resident path): concurrent DP consumers
 struct Lane {
-    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t fork = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
+    static constexpr int kSide = 1;
+    hipStream_t side[kSide] = {nullptr};
+    hipEvent_t fork = nullptr, join[kSide] = {nullptr};
     int init() {
         if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return fail(VF_EDEVICE, "hipEventCreate failed");
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < kSide; ++i) {
             if (hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess) return fail(VF_EDEVICE, "hipStreamCreate failed");
             if (hipEventCreateWithFlags(&join[i], hipEventDisableTiming) != hipSuccess) return fail(VF_EDEVICE, "hipEventCreate failed");
         }
         return VF_OK;
     }
     void destroy() {
-        for (int i = 0; i < 4; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (join[i]) (void)hipEventDestroy(join[i]); }
+        for (int i = 0; i < kSide; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (join[i]) (void)hipEventDestroy(join[i]); }
         if (fork) (void)hipEventDestroy(fork);
     }
 };
@@ -237,8 +238,9 @@ struct vf_ctx {
     hipStream_t main_stream = nullptr;
     Lane main_lane;
     hipEvent_t clear_event = nullptr;   // recorded on main_stream after each table clear
-    ResLane res[2];              // vf_process_device_packed: batch k+1's scan/DP overlaps batch k's finish
-    uint32_t res_next = 0;
+    static constexpr int kMaxResLanes = 4;
+    ResLane res[kMaxResLanes];   // vf_process_device_packed: batch k+1's scan/DP overlaps batch k's finish
+    uint32_t n_res = 2, res_next = 0;
     DevBuf<uint64_t> exp_refs, exp_counts;
     // stats / profiling
     std::atomic<uint64_t> n_reads{0}, n_generic{0};
@@ -373,7 +375,8 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->main_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->clear_event, hipEventDisableTiming));
     if ((rc = c->main_lane.init())) return rc;
-    for (int i = 0; i < 2; ++i) {
+    if (const char *e = getenv("VFIND_RES_LANES")) c->n_res = (uint32_t)std::min(std::max(atoi(e), 1), (int)vf_ctx::kMaxResLanes);
+    for (uint32_t i = 0; i < c->n_res; ++i) {
         ResLane &L = c->res[i];
         HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
@@ -452,7 +455,7 @@ extern "C" void vf_ctx_destroy(vf_ctx *c) {
         if (s->done) (void)hipEventDestroy(s->done);
         if (s->stream) (void)hipStreamDestroy(s->stream);
     }
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < vf_ctx::kMaxResLanes; ++i) {
         ResLane &L = c->res[i];
         L.ws.release(); L.lane.destroy(); L.h_entries.release();
         if (L.done) (void)hipEventDestroy(L.done);
@@ -504,7 +507,7 @@ struct Timed {
 // ------------------------------------------------------------------------------------------------
 static int sync_all_streams(vf_ctx *c) {
     for (auto &s : c->slots) HIP_TRY(hipStreamSynchronize(s->stream));
-    for (auto &L : c->res) HIP_TRY(hipStreamSynchronize(L.stream));
+    for (auto &L : c->res) if (L.stream) HIP_TRY(hipStreamSynchronize(L.stream));
     HIP_TRY(hipStreamSynchronize(c->main_stream));
     return VF_OK;
 }
@@ -567,17 +570,18 @@ static int run_packed(vf_ctx *c, hipStream_t st, Lane &lane, uint32_t chunk_row,
         Timed t(c, st, role == 0 ? K_DPP : K_DPS);
         if (c->filter_on) {
             // The five consumers of the filter's lists (four window classes + the full-width rest) are
-            // independent; only the first class is big.  They run side by side on the lane's streams so
-            // the small, latency-bound launches hide under the big one instead of queueing behind it.
+            // independent; only the first class is big.  The four small, latency-bound ones run back to
+            // back on the lane's side stream, next to the big one (one side stream per lane: the device
+            // exposes four hardware queues, more streams than that alias and serialise).
             HIP_TRY(launch_filter(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters));
             HIP_TRY(hipEventRecord(lane.fork, st));
-            for (int q = 0; q < 5; ++q) {
-                hipStream_t sq = q == 0 ? st : lane.side[q - 1];
-                if (q) HIP_TRY(hipStreamWaitEvent(sq, lane.fork, 0));
-                if (q < 4) HIP_TRY(launch_dp_window(sq, q, W, d_rows, d_lens, dp, d_spans, bl));
-                else HIP_TRY(launch_dp(sq, W, d_rows, d_lens, dp, d_spans, bl, true, c->tab.counters));
-                if (q) { HIP_TRY(hipEventRecord(lane.join[q - 1], sq)); HIP_TRY(hipStreamWaitEvent(st, lane.join[q - 1], 0)); }
-            }
+            hipStream_t side = lane.side[0];
+            HIP_TRY(hipStreamWaitEvent(side, lane.fork, 0));
+            HIP_TRY(launch_dp_window(st, 0, W, d_rows, d_lens, dp, d_spans, bl));             // the big class
+            for (int q = 1; q < 4; ++q) HIP_TRY(launch_dp_window(side, q, W, d_rows, d_lens, dp, d_spans, bl));
+            HIP_TRY(launch_dp(side, W, d_rows, d_lens, dp, d_spans, bl, true, c->tab.counters));
+            HIP_TRY(hipEventRecord(lane.join[0], side));
+            HIP_TRY(hipStreamWaitEvent(st, lane.join[0], 0));
         } else {
             HIP_TRY(launch_dp(st, W, d_rows, d_lens, dp, d_spans, bl, false, c->tab.counters));
         }
@@ -827,7 +831,7 @@ extern "C" int vf_process_device_packed(vf_ctx *c, const void *d_rows, uint32_t 
     if (W != 10 && W != 20 && W != 40) return fail(VF_EINVAL, "row_dwords must be 10, 20 or 40");
     HIP_TRY(hipSetDevice(c->dev));
     int rc;
-    ResLane &L = c->res[c->res_next++ & 1u];
+    ResLane &L = c->res[c->res_next++ % c->n_res];
     if (L.in_flight && hipEventQuery(L.done) == hipSuccess) {           // lane idle: its entry count is current
         if ((rc = table_grow_if_needed(c, *L.h_entries.p))) return rc;
     }
@@ -864,6 +868,7 @@ extern "C" int vf_sync(vf_ctx *c) {
         s->in_flight = false;
     }
     for (auto &L : c->res) {
+        if (!L.stream) continue;
         HIP_TRY(hipStreamSynchronize(L.stream));
         L.in_flight = false;
     }

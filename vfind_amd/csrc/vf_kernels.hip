@@ -13,6 +13,8 @@
 //   k_export / k_merge   table compaction and (key,count) merge for the multi-GPU exchange
 #include "vf_device.h"
 
+#include <cstdlib>
+
 namespace vf {
 
 #define WAVE 64
@@ -1414,7 +1416,8 @@ hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint1
     if (n == 0) return hipSuccess;
     hipError_t e = ensure_lut();
     if (e != hipSuccess) return e;
-    const int g = grid_for(n, 8);
+    static const int per_cu = [] { const char *v = getenv("VFIND_FINISH_BLOCKS_PER_CU"); const int x = v ? atoi(v) : 8; return x >= 1 && x <= 8 ? x : 8; }();
+    const int g = grid_for(n, per_cu);
     switch (W) {
     case 10: hipLaunchKernelGGL(k_finish<10>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, skip_translation, t); break;
     case 20: hipLaunchKernelGGL(k_finish<20>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, skip_translation, t); break;
