@@ -103,6 +103,7 @@ def main():
     # ---- parity gate (rank 0): device path == CPU oracle on a sample of the same reads -----------
     parity = None
     cpu = None
+    oracle_full, oracle_full_n = None, 0
     if rank == 0 and not (args.no_parity and args.no_cpu_baseline):
         from oracle import oracle          # the checker / CPU baseline; never part of the timed GPU path
         cores = min(os.cpu_count() or 1, 16)          # a 1-GPU box gives this job a 16-core share
@@ -125,9 +126,10 @@ def main():
             best = None
             for _ in range(2):
                 tq = time.perf_counter()
-                oracle.count((sb, so), ads, n_threads=cores)
+                oracle_full = oracle.count((sb, so), ads, n_threads=cores)
                 dt = time.perf_counter() - tq
                 best = dt if best is None else min(best, dt)
+            oracle_full_n = sample
             cpu = {"value": round(sample / best / 1e6, 4), "unit": "M reads/s", "cores": cores, "kind": "port",
                    "sample": f"first {sample} reads of the same workload, all {cores} host threads, best of 2; "
                              "CPU restatement of vfind 0.3.1 (reference not buildable: no rustc/parasail)"}
@@ -156,6 +158,15 @@ def main():
     eng.set_profiling(False)
     st = eng.stats()
 
+    # ---- full-size parity: the table left by the last timed step (resident packed path, all n reads)
+    # against the oracle's table of the same reads, when the CPU baseline sample covered them all
+    parity_full = None
+    if rank == 0 and oracle_full is not None and oracle_full_n == n and not args.no_parity:
+        parity_full = eng.finish_dict() == oracle_full
+        if not parity_full:
+            raise SystemExit("PARITY FAILED at full size: device table differs from the CPU oracle")
+    oracle_full = None
+
     # ---- final (key,count) merge across GPUs over RCCL (xGMI), timed separately ------------------
     merge_ms = None
     counted_local = st["counted"] // max(args.steps, 1)
@@ -179,19 +190,19 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * n * args.steps / elapsed / 1e6
-        kern = {
-            "scan": (st["ms_scan"], st["launches_scan"], n * b_alg(L)),
-            "dp_prefix": (st["ms_dp_prefix"], st["launches_dp_prefix"], None),
-            "dp_suffix": (st["ms_dp_suffix"], st["launches_dp_suffix"], None),
-            "finish": (st["ms_finish"], st["launches_finish"], None),
-        }
-        # per-launch algorithmic bytes of the DP kernels: each task reads its packed row (+2-byte
-        # length, 4-byte task index) and writes one 4-byte span; finish: span in + accepted rows in
+        # per kernel: (summed event ms, launches, algorithmic bytes per launch).  A DP task reads its packed
+        # row (+2-byte length, 4-byte task index, 4-byte window) and writes one 4-byte span; the filter
+        # and the two DP groups run once per adapter, so their per-launch task count is the mean of both.
         row_b = (2 * L + 7) // 8
         steps = max(args.steps, 1)
-        kern["dp_prefix"] = (kern["dp_prefix"][0], kern["dp_prefix"][1], st["dp_prefix"] / steps * (row_b + 10))
-        kern["dp_suffix"] = (kern["dp_suffix"][0], kern["dp_suffix"][1], st["dp_suffix"] / steps * (row_b + 10))
-        kern["finish"] = (kern["finish"][0], kern["finish"][1], n * 4 + st["accepted"] / steps * (row_b + 2))
+        tasks = (st["dp_prefix"] + st["dp_suffix"]) / steps / 2
+        kern = {
+            "scan": (st["ms_scan"], st["launches_scan"], n * b_alg(L)),
+            "filter": (st["ms_filter"], st["launches_filter"], tasks * (row_b + 10)),
+            "dp_window": (st["ms_dp_window"], st["launches_dp_window"], tasks * (row_b + 14)),
+            "dp_rest": (st["ms_dp_rest"], st["launches_dp_rest"], tasks * (row_b + 14)),
+            "finish": (st["ms_finish"], st["launches_finish"], n * 4 + st["accepted"] / steps * (row_b + 2)),
+        }
         dom = max(kern, key=lambda k: kern[k][0])
         ms_tot, launches, bytes_per_launch = kern[dom]
         avg_ms = ms_tot / max(launches, 1)
@@ -223,7 +234,7 @@ def main():
                               "frac": round(path_gbps / HBM_PEAK_GBPS, 6), "alg_bytes_per_read": b_alg(L),
                               "kernel_ms_per_step": {k: round(v[0] / steps, 4) for k, v in kern.items()}},
             "cpu_baseline": cpu,
-            "parity_gate": parity,
+            "parity_gate": parity, "parity_full_size": parity_full,
             "merge_ms": None if merge_ms is None else round(merge_ms, 3),
             "per_step": {"dp_prefix_tasks": st["dp_prefix"] // steps, "dp_suffix_tasks": st["dp_suffix"] // steps,
                          "accepted": st["accepted"] // steps, "counted": st["counted"] // steps,

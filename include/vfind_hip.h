@@ -73,10 +73,11 @@ typedef struct vf_stats {
     uint64_t counted;          /* reads that incremented a key (after the len%3 drop)    */
     uint64_t table_entries;    /* distinct keys on the device                            */
     uint64_t arena_dwords;     /* total key dwords held by the table                     */
-    /* device time per kernel, milliseconds, summed over launches (HIP events on the
-       context's stream; filled only while profiling is on) */
-    double ms_scan, ms_dp_prefix, ms_dp_suffix, ms_finish, ms_generic;
-    uint64_t launches_scan, launches_dp_prefix, launches_dp_suffix, launches_finish, launches_generic;
+    /* device time per kernel, milliseconds, summed over launches (HIP events on the stream the kernel
+       is launched on; filled only while profiling is on).  dp_window = the big window class (both
+       adapters), dp_rest = the side stream's group of small window classes + full-width DP */
+    double ms_scan, ms_filter, ms_dp_window, ms_dp_rest, ms_finish, ms_generic;
+    uint64_t launches_scan, launches_filter, launches_dp_window, launches_dp_rest, launches_finish, launches_generic;
 } vf_stats;
 
 const char *vf_last_error(void);

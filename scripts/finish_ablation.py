@@ -20,5 +20,5 @@ for skip in (False, True):
                 eng.clear()
             eng.process_device(rows.data_ptr(), gen.row_dwords, lens.data_ptr(), n)
         eng.sync(); st = eng.stats(); eng.set_profiling(False)
-        print(f"skip_translation={skip} {mode}: finish {st['ms_finish']/3:.3f} ms scan {st['ms_scan']/3:.3f} dpP {st['ms_dp_prefix']/3:.3f} dpS {st['ms_dp_suffix']/3:.3f} entries {st['table_entries']}", flush=True)
+        print(f"skip_translation={skip} {mode}: finish {st['ms_finish']/3:.3f} ms scan {st['ms_scan']/3:.3f} filter {st['ms_filter']/3:.3f} dpw {st['ms_dp_window']/3:.3f} dp_rest {st['ms_dp_rest']/3:.3f} entries {st['table_entries']}", flush=True)
     eng.close()

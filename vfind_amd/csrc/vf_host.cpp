@@ -102,7 +102,7 @@ extern "C" int vf_pack_read(const uint8_t *seq, uint32_t n, uint32_t *row, uint3
 namespace {
 
 struct EventPair { hipEvent_t a, b; int kind; };
-enum { K_SCAN = 0, K_DPP, K_DPS, K_FIN, K_GEN, K_KINDS };
+enum { K_SCAN = 0, K_FILTER, K_DPW, K_DPREST, K_FIN, K_GEN, K_KINDS };
 
 template <typename T> struct DevBuf {
     T *p = nullptr;
@@ -247,8 +247,8 @@ struct vf_ctx {
     bool profiling = false;
     std::mutex ev_mu;
     std::vector<EventPair> pending_events;
-    double ms[K_KINDS] = {0, 0, 0, 0, 0};
-    uint64_t launches[K_KINDS] = {0, 0, 0, 0, 0};
+    double ms[K_KINDS] = {0, 0, 0, 0, 0, 0};
+    uint64_t launches[K_KINDS] = {0, 0, 0, 0, 0, 0};
     // async error from worker threads
     // table growth: submitters hold it shared while they enqueue, table_grow exclusively
     std::shared_mutex table_mu;
@@ -567,22 +567,25 @@ static int run_packed(vf_ctx *c, hipStream_t st, Lane &lane, uint32_t chunk_row,
     for (int role = 0; role < 2; ++role) {
         if (role == 0 ? c->skip_pre : c->skip_suf) continue;
         const DpParams &dp = role == 0 ? dpP : dpS;
-        Timed t(c, st, role == 0 ? K_DPP : K_DPS);
         if (c->filter_on) {
             // The five consumers of the filter's lists (four window classes + the full-width rest) are
             // independent; only the first class is big.  The four small, latency-bound ones run back to
             // back on the lane's side stream, next to the big one (one side stream per lane: the device
             // exposes four hardware queues, more streams than that alias and serialise).
-            HIP_TRY(launch_filter(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters));
+            { Timed t(c, st, K_FILTER); HIP_TRY(launch_filter(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters)); }
             HIP_TRY(hipEventRecord(lane.fork, st));
             hipStream_t side = lane.side[0];
             HIP_TRY(hipStreamWaitEvent(side, lane.fork, 0));
-            HIP_TRY(launch_dp_window(st, 0, W, d_rows, d_lens, dp, d_spans, bl));             // the big class
-            for (int q = 1; q < 4; ++q) HIP_TRY(launch_dp_window(side, q, W, d_rows, d_lens, dp, d_spans, bl));
-            HIP_TRY(launch_dp(side, W, d_rows, d_lens, dp, d_spans, bl, true, c->tab.counters));
+            { Timed t(c, st, K_DPW); HIP_TRY(launch_dp_window(st, 0, W, d_rows, d_lens, dp, d_spans, bl)); }      // the big class
+            {
+                Timed t(c, side, K_DPREST);
+                for (int q = 1; q < 4; ++q) HIP_TRY(launch_dp_window(side, q, W, d_rows, d_lens, dp, d_spans, bl));
+                HIP_TRY(launch_dp(side, W, d_rows, d_lens, dp, d_spans, bl, true, c->tab.counters));
+            }
             HIP_TRY(hipEventRecord(lane.join[0], side));
             HIP_TRY(hipStreamWaitEvent(st, lane.join[0], 0));
         } else {
+            Timed t(c, st, K_DPREST);
             HIP_TRY(launch_dp(st, W, d_rows, d_lens, dp, d_spans, bl, false, c->tab.counters));
         }
     }
@@ -1039,11 +1042,11 @@ extern "C" int vf_stats_get(vf_ctx *c, vf_stats *o) {
     o->dp_prefix = h[C_DP_PREFIX]; o->dp_suffix = h[C_DP_SUFFIX];
     o->accepted = h[C_ACCEPTED]; o->counted = h[C_COUNTED];
     o->table_entries = h[C_ENTRIES]; o->arena_dwords = h[C_KEY_DWORDS];
-    o->ms_scan = c->ms[K_SCAN]; o->ms_dp_prefix = c->ms[K_DPP]; o->ms_dp_suffix = c->ms[K_DPS];
+    o->ms_scan = c->ms[K_SCAN]; o->ms_filter = c->ms[K_FILTER]; o->ms_dp_window = c->ms[K_DPW]; o->ms_dp_rest = c->ms[K_DPREST];
     o->ms_finish = c->ms[K_FIN]; o->ms_generic = c->ms[K_GEN];
-    o->launches_scan = c->launches[K_SCAN]; o->launches_dp_prefix = c->launches[K_DPP];
-    o->launches_dp_suffix = c->launches[K_DPS]; o->launches_finish = c->launches[K_FIN];
-    o->launches_generic = c->launches[K_GEN];
+    o->launches_scan = c->launches[K_SCAN]; o->launches_filter = c->launches[K_FILTER];
+    o->launches_dp_window = c->launches[K_DPW]; o->launches_dp_rest = c->launches[K_DPREST];
+    o->launches_finish = c->launches[K_FIN]; o->launches_generic = c->launches[K_GEN];
     return VF_OK;
 }
 extern "C" int vf_stats_reset(vf_ctx *c) {
