@@ -347,12 +347,32 @@ def test_table_grows_between_batches():
 
 
 def test_capacity_error_is_loud():
-    from vfind_amd import Engine, VfindError
+    """streaming submits reserve room before they are enqueued (the table grows first), so a tiny table
+    still gives the oracle's answer; a resident batch larger than the table cannot be saved and fails loudly,
+    (the key arena for long keys grows with the streaming path as well)"""
+    import torch
+    from vfind_amd import Engine, VfindError, synth as vsynth
     reads = synth.make_reads(95, 4000, AD20, L=150, n_variants=2000)
-    with Engine(AD20, skip_translation=True, table_slots=64, arena_bytes=1 << 20) as e:
+    with Engine(AD20, skip_translation=True, table_slots=64, batch_reads=512) as e:
         e.submit(reads)
-        with pytest.raises(VfindError, match="table full|arena full"):
+        assert e.finish_dict() == oracle.count(reads, AD20, skip_translation=True)
+        assert e.stats()["table_entries"] > 64
+    gen = vsynth.Generator(7, AD20, n_variants=3000)
+    rows, lens = gen.packed(0, 20000, 4)
+    d_rows = torch.from_numpy(rows).cuda()
+    d_lens = torch.from_numpy(lens.view("int16")).cuda()
+    with Engine(AD20, table_slots=64) as e:
+        e.process_device(d_rows.data_ptr(), rows.shape[1], d_lens.data_ptr(), 20000)
+        with pytest.raises(VfindError, match="table full"):
             e.finish_dict()
+    # long keys live in the key arena, which grows the same way for streaming submits
+    long_reads = synth.make_reads(96, 3000, AD20, L=600, n_variants=3000)
+    with Engine(AD20, skip_translation=True, arena_bytes=1 << 12, table_slots=1 << 14) as e:
+        e.submit(long_reads)
+        got = e.finish_dict()
+        assert e.stats()["arena_dwords"] > (1 << 10)
+    assert got == oracle.count(long_reads, AD20, skip_translation=True)
+    assert max(len(k) for k in got) > 224
 
 
 def test_arrow_export_frame():

@@ -80,6 +80,7 @@ enum Counter : int {        // uint64 counters[] in device memory
 };
 constexpr int kTableCounters = 4;       // C_ARENA_TOP..C_KEY_DWORDS are reset with the table
 
+constexpr uint32_t kChunk = 1024;       // dwords of key arena a workgroup takes per refill (arena_alloc)
 constexpr uint32_t kChunkRows = 21;     // chunk-state rows: 16 batch streams, the main stream, 4 resident lanes
 
 struct Table {

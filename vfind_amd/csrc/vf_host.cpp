@@ -252,6 +252,10 @@ struct vf_ctx {
     // async error from worker threads
     // table growth: submitters hold it shared while they enqueue, table_grow exclusively
     std::shared_mutex table_mu;
+    std::mutex cap_mu;                          // guards the two counters below
+    uint64_t upper_entries = 0;                 // entries at the last exact count + every read submitted since
+    uint64_t unenqueued = 0;                    // reads of submitters between their capacity check and their enqueue
+    uint64_t upper_arena = 0, unenqueued_arena = 0;   // the same pair for key-arena dwords
     std::mutex err_mu;
     int async_rc = 0;
     std::string async_msg;
@@ -414,7 +418,7 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     uint64_t pow2 = 1; while (pow2 < slots) pow2 <<= 1;
     if (pow2 > (1ull << 32)) return fail(VF_EINVAL, "table_slots too large");
     c->table_slots = pow2;
-    c->arena_dwords = (p->arena_bytes ? p->arena_bytes : (1ull << 28)) / 4;
+    c->arena_dwords = (p->arena_bytes ? p->arena_bytes : (1ull << 30)) / 4;
     if ((rc = c->t_slots.ensure(c->table_slots * 4))) return rc;
     if ((rc = c->t_counts.ensure(c->table_slots))) return rc;
     if ((rc = c->t_arena.ensure(c->arena_dwords))) return rc;
@@ -512,14 +516,35 @@ static int sync_all_streams(vf_ctx *c) {
     return VF_OK;
 }
 
-static int table_grow_if_needed(vf_ctx *c, uint64_t entries_hint) {
-    if (entries_hint * 2 <= c->table_slots) return VF_OK;
-    std::unique_lock<std::shared_mutex> lk(c->table_mu);          // no submitter is enqueueing now
+// every (stream row, workgroup) that has not taken an arena chunk yet may take one for a single key
+static inline uint64_t arena_slack(const vf_ctx *c) { return (uint64_t)(c->queue_len + vf_ctx::kMaxResLanes + 1) * kMaxGrid * kChunk; }
+
+// grows until (entries + extra) fits in half the slots; extra = reads about to be submitted (each may be a
+// new key).  Takes the table lock exclusively: no submitter is enqueueing while the table is swapped.
+static int table_grow_locked(vf_ctx *c, bool use_unenqueued, uint64_t extra) {
+    std::unique_lock<std::shared_mutex> lk(c->table_mu);
     int rc;
     if ((rc = sync_all_streams(c))) return rc;
     uint64_t h[C_NUM];
     HIP_TRY(hipMemcpy(h, c->t_counters.p, sizeof(h), hipMemcpyDeviceToHost));
-    while (h[C_ENTRIES] * 2 > c->table_slots) {
+    uint64_t extra_arena = 0;
+    if (use_unenqueued) { std::lock_guard<std::mutex> g(c->cap_mu); extra = c->unenqueued; extra_arena = c->unenqueued_arena; }
+    // key arena: offsets stay valid, so growing is a copy
+    if (extra_arena) {
+        uint64_t cap = c->arena_dwords;
+        while (h[C_ARENA_TOP] + extra_arena + arena_slack(c) > cap) cap *= 4;
+        if (cap != c->arena_dwords) {
+            if (cap > (1ull << 36)) return fail(VF_ECAPACITY, "device key arena cannot grow beyond 256 GiB");
+            DevBuf<uint32_t> n_arena;
+            if ((rc = n_arena.ensure(cap))) return rc;
+            HIP_TRY(hipMemcpy(n_arena.p, c->t_arena.p, std::min<uint64_t>(h[C_ARENA_TOP], c->arena_dwords) * 4, hipMemcpyDeviceToDevice));
+            c->t_arena.release();
+            c->t_arena = n_arena;
+            c->arena_dwords = cap;
+            c->tab.arena = c->t_arena.p; c->tab.arena_cap = cap;
+        }
+    }
+    while ((h[C_ENTRIES] + extra) * 2 > c->table_slots) {
         const uint64_t new_slots = c->table_slots * 4;
         if (new_slots > (1ull << 32)) return fail(VF_ECAPACITY, "device count table cannot grow beyond 2^32 slots");
         DevBuf<uint4> n_slots; DevBuf<uint64_t> n_counts;
@@ -539,9 +564,42 @@ static int table_grow_if_needed(vf_ctx *c, uint64_t entries_hint) {
         c->tab = to;
         HIP_TRY(hipMemcpy(h, c->t_counters.p, sizeof(h), hipMemcpyDeviceToHost));
     }
+    { std::lock_guard<std::mutex> g(c->cap_mu); c->upper_entries = h[C_ENTRIES] + c->unenqueued; c->upper_arena = h[C_ARENA_TOP] + c->unenqueued_arena; }
     for (auto &s : c->slots) if (s->h_entries.p) *s->h_entries.p = h[C_ENTRIES];
     for (auto &L : c->res) if (L.h_entries.p) *L.h_entries.p = h[C_ENTRIES];
     return VF_OK;
+}
+
+// resident path: the previous batch brought the entry count back; grow when more than half is used
+static int table_grow_if_needed(vf_ctx *c, uint64_t entries_hint) {
+    if (entries_hint * 2 <= c->table_slots) return VF_OK;
+    return table_grow_locked(c, false, 0);
+}
+
+// streaming paths: every read of a batch may add a key, so a batch is only enqueued when the table
+// could take all of them (a conservative count, refreshed from the device whenever it runs out)
+struct CapacityTicket {
+    vf_ctx *c; uint64_t n = 0, arena = 0;
+    ~CapacityTicket() { if (n) { std::lock_guard<std::mutex> g(c->cap_mu); c->unenqueued -= n; c->unenqueued_arena -= arena; } }
+};
+// worst-case arena dwords one read can take: only keys longer than the 14 inline dwords go there
+// (56 letters = 168 bases translated, 224 bases untranslated); a workgroup wastes < 1/4 chunk per refill,
+// keys beyond a quarter chunk take whole chunks
+static inline uint64_t arena_need(const vf_ctx *c, uint32_t len) {
+    if (len <= (c->skip_translation ? 224u : 168u)) return 0;
+    const uint64_t nd = c->skip_translation ? (len + 15) / 16 : (len / 3 + 3) / 4;
+    return nd > kChunk / 4 ? nd + kChunk : nd + nd / 3 + 1;
+}
+static int reserve_capacity(vf_ctx *c, CapacityTicket &t, uint64_t n, uint64_t arena) {
+    uint64_t up, upa;
+    {
+        std::lock_guard<std::mutex> g(c->cap_mu);
+        t.n = n; t.arena = arena;
+        c->unenqueued += n; c->unenqueued_arena += arena;
+        up = (c->upper_entries += n); upa = (c->upper_arena += arena);
+    }
+    if (up * 2 <= c->table_slots && (!arena || upa + arena_slack(c) <= c->arena_dwords)) return VF_OK;
+    return table_grow_locked(c, true, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -662,7 +720,12 @@ static int submit_chunk(vf_ctx *c, const uint8_t *base, const ReadRef *reads, ui
     struct Rel { vf_ctx *c; Slot *s; ~Rel() { release_slot(c, s); } } rel{c, s};
     int rc;
     if ((rc = wait_slot(s))) return rc;
-    if ((rc = table_grow_if_needed(c, *s->h_entries.p))) return rc;
+    CapacityTicket ticket{c};
+    if (!spans_mode) {
+        uint64_t need = 0;
+        for (uint64_t i = 0; i < n; ++i) need += arena_need(c, reads[i].len);
+        if ((rc = reserve_capacity(c, ticket, n, need))) return rc;
+    }
     std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
 
     // geometry of the fast part
@@ -800,7 +863,10 @@ extern "C" int vf_submit_packed(vf_ctx *c, const uint32_t *rows, uint32_t W, con
         struct Rel { vf_ctx *c; Slot *s; ~Rel() { release_slot(c, s); } } rel{c, s};
         int rc;
         if ((rc = wait_slot(s))) return rc;
-        if ((rc = table_grow_if_needed(c, *s->h_entries.p))) return rc;
+        CapacityTicket ticket{c};
+        uint64_t need = 0;
+        for (uint64_t i = 0; i < m; ++i) need += arena_need(c, lens[lo + i]);
+        if ((rc = reserve_capacity(c, ticket, m, need))) return rc;
         std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
         if ((rc = s->h_rows.ensure((size_t)m * W))) return rc;
         if ((rc = s->h_lens.ensure(m))) return rc;
@@ -893,6 +959,7 @@ extern "C" int vf_table_clear(vf_ctx *c) {
     for (auto &L : c->res)
         if (L.in_flight) HIP_TRY(hipStreamWaitEvent(c->main_stream, L.done, 0));
     std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
+    { std::lock_guard<std::mutex> g(c->cap_mu); c->upper_entries = c->unenqueued; c->upper_arena = c->unenqueued_arena; }
     return table_clear_locked(c);
 }
 

@@ -737,7 +737,6 @@ __device__ __forceinline__ unsigned long long *slot_count(const Table &t, uint32
 // bump pointer.  The chunk state survives across launches in t.chunk_state[row][block], one row per
 // stream, so the arena loses at most one partial chunk per (stream, workgroup) in total.
 //   state = (chunk_index + 1) << 32 | dwords_used      (0 = no chunk yet)
-constexpr uint32_t kChunk = 4096;            // dwords
 struct BlockTable {
     unsigned long long chunk;                // LDS copy of the chunk state
     uint32_t new_entries;                    // keys inserted by this workgroup (flushed at kernel end)
