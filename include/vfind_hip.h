@@ -54,8 +54,8 @@ typedef struct vf_params {
     uint32_t queue_len;              /* batches in flight per GPU (lib.rs:179), default 2 */
     int32_t skip_translation;        /* lib.rs:180 */
     int32_t device;                  /* HIP device ordinal */
-    uint64_t table_slots;            /* count-table slots (64 B + 8 B each), power of two; 0 = 2^24 */
-    uint64_t arena_bytes;            /* arena for keys longer than 56 bytes; 0 = 256 MiB */
+    uint64_t table_slots;            /* initial count-table slots (64 B + 8 B each), power of two; 0 = 2^24; grows x4 on demand */
+    uint64_t arena_bytes;            /* initial arena for keys longer than 56 bytes; 0 = 1 GiB; grows x4 on demand */
     uint32_t batch_reads;            /* reads per device batch; 0 = 2^18 */
     uint32_t reserved;
 } vf_params;
