@@ -137,8 +137,11 @@ def main():
         del pb, po
     eng.reset_stats()
 
+    keep_table = os.environ.get("VFIND_BENCH_KEEP_TABLE") == "1"      # experiment only: steps then count into a warm table
+
     def step():
-        eng.clear()
+        if not keep_table:
+            eng.clear()
         eng.process_device(rows.data_ptr(), gen.row_dwords, lens.data_ptr(), n)
 
     for _ in range(args.warmup):
@@ -161,7 +164,7 @@ def main():
     # ---- full-size parity: the table left by the last timed step (resident packed path, all n reads)
     # against the oracle's table of the same reads, when the CPU baseline sample covered them all
     parity_full = None
-    if rank == 0 and oracle_full is not None and oracle_full_n == n and not args.no_parity:
+    if rank == 0 and oracle_full is not None and oracle_full_n == n and not args.no_parity and not keep_table:
         parity_full = eng.finish_dict() == oracle_full
         if not parity_full:
             raise SystemExit("PARITY FAILED at full size: device table differs from the CPU oracle")
@@ -234,7 +237,7 @@ def main():
                               "frac": round(path_gbps / HBM_PEAK_GBPS, 6), "alg_bytes_per_read": b_alg(L),
                               "kernel_ms_per_step": {k: round(v[0] / steps, 4) for k, v in kern.items()}},
             "cpu_baseline": cpu,
-            "parity_gate": parity, "parity_full_size": parity_full,
+            "parity_gate": parity, "parity_full_size": parity_full, "table_cleared_each_step": not keep_table,
             "merge_ms": None if merge_ms is None else round(merge_ms, 3),
             "per_step": {"dp_prefix_tasks": st["dp_prefix"] // steps, "dp_suffix_tasks": st["dp_suffix"] // steps,
                          "accepted": st["accepted"] // steps, "counted": st["counted"] // steps,

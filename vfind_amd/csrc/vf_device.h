@@ -114,7 +114,7 @@ hipError_t launch_dp_window(hipStream_t s, int cls, int W, const uint32_t *rows,
 hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
                      short2 *spans, BatchLists bl, bool from_filter, uint64_t *counters);
 hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n,
-                         const short2 *spans, uint32_t skip_translation, Table t);
+                         const short2 *spans, bool skip_translation, Table t);
 hipError_t launch_generic(hipStream_t s, const uint8_t *bytes, const uint64_t *offs, uint64_t n,
                           const GenericParams &gp, int32_t *starts, int32_t *ends, int32_t *ws,
                           uint64_t ws_stride, uint32_t ws_rows, Table t);

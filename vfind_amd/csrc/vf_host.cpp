@@ -219,7 +219,6 @@ struct vf_ctx {
     int64_t T_pre = 0, T_suf = 0;
     bool skip_translation = false;
     bool fast_ok = false;
-    uint32_t debug_flags = 0;    // VFIND_DEBUG_FLAGS: profiling aids for k_finish (0x100 no table, 0x200 no count)
     bool filter_on = false;      // Myers pre-DP filter + windowed DP usable for these scores
     uint32_t n_threads = 3, queue_len = 2, batch_reads = 1u << 18;
     ScanParams sp{};
@@ -362,7 +361,6 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     c->queue_len = std::min<uint32_t>(std::max<uint32_t>(p->queue_len, 1), 16);
     c->batch_reads = p->batch_reads ? p->batch_reads : (1u << 18);
     c->dev = p->device;
-    if (const char *dbg = getenv("VFIND_DEBUG_FLAGS")) c->debug_flags = (uint32_t)strtoul(dbg, nullptr, 0) & 0xFF00u;
 
     // can the 2-bit fast path hold these adapters and scores?  (else every read goes byte-wise)
     auto small = [](int32_t v) { return v >= -127 && v <= 127; };
@@ -651,7 +649,7 @@ static int run_packed(vf_ctx *c, hipStream_t st, Lane &lane, uint32_t chunk_row,
     tab.chunk_row = chunk_row;
     // only the table kernels are ordered after the latest clear; scan and DP may overlap it
     if (count) HIP_TRY(hipStreamWaitEvent(st, c->clear_event, 0));
-    if (count) { Timed t(c, st, K_FIN); HIP_TRY(launch_finish(st, W, d_rows, d_lens, n, d_spans, (c->skip_translation ? 1u : 0u) | c->debug_flags, tab)); }
+    if (count) { Timed t(c, st, K_FIN); HIP_TRY(launch_finish(st, W, d_rows, d_lens, n, d_spans, c->skip_translation, tab)); }
     // the entry count rides back with the batch: the host grows the table between batches when it fills
     if (count && h_entries) HIP_TRY(hipMemcpyAsync(h_entries, c->t_counters.p + C_ENTRIES, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     return VF_OK;

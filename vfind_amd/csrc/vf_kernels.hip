@@ -73,62 +73,117 @@ template <int W> __device__ __forceinline__ void load_row(const uint32_t *rows, 
 
 // ------------------------------------------------------------------------------------------------
 // exact leftmost search of an m-base pattern in a packed read (memmem::find, lib.rs:148)
-// XOR-accumulate over pattern bases: acc slot p (2 bits) stays 0 iff read[p+j]==pat[j] for all j
+//
+// Stage 1 compares only (up to) eight bases of each pattern at every start position: XOR-accumulate
+// over those bases, acc slot p (2 bits) stays 0 iff read[p+j] == pat[j] for every checked j.  The
+// checked bases are pairs (b, b+16) where the pattern is long enough - both sit at the same bit shift
+// of the read, one word apart, so a pair costs one funnel shift - and single bases otherwise.
+// Stage 2 walks the surviving start positions from the left and compares the whole pattern against
+// the read's own bits; the first one that matches is memmem's answer.  A random position survives
+// stage 1 with probability 4^-8, so stage 2 almost always runs once per adapter.
+// Pattern constants are moved to VGPRs: VALU instructions with an SGPR operand issue at half rate.
 // ------------------------------------------------------------------------------------------------
-template <int W> __device__ __forceinline__ int first_hit(const uint32_t (&acc)[W], int n, int m) {
-    const int limit = n - m + 1;          // number of valid start positions
-    int pos = -1;
+__device__ __forceinline__ uint32_t to_vgpr_u(uint32_t s) {
+    uint32_t v;
+    asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
+struct ScanPlan { int nlo, nhi; };                      // bases b < nlo and b+16 for b < nhi are checked
+__device__ __forceinline__ ScanPlan scan_plan(int m) {
+    const int pairs = max(0, min(4, m - 16));
+    const int lo_room = min(m, 16) - pairs;
+    const int singles = max(0, min(8 - 2 * pairs, lo_room));
+    return ScanPlan{pairs + singles, pairs};
+}
+// candidate start positions: one (even) bit per position, 16 positions a word
+template <int W> __device__ __forceinline__ void scan_candidates(const uint32_t (&acc)[W], uint32_t (&h)[W]) {
 #pragma unroll
-    for (int w = W - 1; w >= 0; --w) {
-        const uint32_t a = acc[w];
-        uint32_t hit = ~(a | (a >> 1)) & 0x55555555u;
-        const int cnt = limit - 16 * w;
-        const uint32_t mask = cnt >= 16 ? 0xFFFFFFFFu : (cnt <= 0 ? 0u : ((1u << (2 * cnt)) - 1u));
-        hit &= mask;
-        if (hit) pos = 16 * w + ((__ffs((int)hit) - 1) >> 1);
+    for (int w = 0; w < W; ++w) h[w] = ~(acc[w] | (acc[w] >> 1)) & 0x55555555u;
+}
+// leftmost candidate, or a value >= 2^30 when there is none (__ffs(0) - 1 = 0xFFFFFFFF)
+template <int W> __device__ __forceinline__ uint32_t first_candidate(const uint32_t (&h)[W]) {
+    uint32_t pos = 0xFFFFFFFFu;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const uint32_t pw = (((uint32_t)(__ffs((int)h[w]) - 1)) >> 1) + 16u * (uint32_t)w;
+        pos = min(pos, pw);
     }
     return pos;
 }
+template <int W> __device__ __forceinline__ void drop_candidate(uint32_t (&h)[W], uint32_t pos) {
+    const uint32_t bit = 1u << (2u * (pos & 15u));
+#pragma unroll
+    for (int w = 0; w < W; ++w) h[w] &= ~((pos >> 4) == (uint32_t)w ? bit : 0u);
+}
+// whole-pattern compare at start position p (p + m <= n <= 16 W)
+template <int W> __device__ __forceinline__ bool verify_at(const uint32_t *__restrict__ row, int p, uint64_t pat, int m) {
+    const int idx = p >> 4;
+    const uint32_t bs = 2u * (uint32_t)(p & 15);
+    const uint32_t d0 = row[idx];
+    const uint32_t d1 = idx + 1 < W ? row[idx + 1] : 0u;
+    const uint32_t d2 = idx + 2 < W ? row[idx + 2] : 0u;
+    const uint32_t lo = funnel(d1, d0, bs), hi = funnel(d2, d1, bs);
+    const uint64_t mask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
+    const uint64_t diff = (((uint64_t)hi << 32 | lo) ^ pat) & mask;
+    return diff == 0ull;
+}
 
-// both adapters in one pass so the funnel-shifted read words are shared (5 ops per word and base)
 template <int W>
-__device__ __forceinline__ void exact_find2(const uint32_t (&r)[W + 2], int n, const ScanParams &sp, int &ps, int &ss) {
+__device__ __forceinline__ void exact_find2(const uint32_t (&r)[W + 2], const uint32_t *__restrict__ row, int n, const ScanParams &sp,
+                                            int &ps, int &ss) {
     uint32_t accP[W], accS[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) { accP[w] = 0; accS[w] = 0; }
     const int mp = (int)sp.pre_len, ms = (int)sp.suf_len;
-    // pattern bases b and b+16 need the same funnel shift (one word apart): compute it once
+    const ScanPlan pp = scan_plan(mp), sq = scan_plan(ms);
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
-        const bool p0 = b < mp, p1 = b + 16 < mp, s0 = b < ms, s1 = b + 16 < ms;     // wave-uniform
+        const bool p0 = b < pp.nlo, p1 = b < pp.nhi, s0 = b < sq.nlo, s1 = b < sq.nhi;       // wave-uniform
         if (p0 || s0) {
             uint32_t xs[W + 1];
 #pragma unroll
             for (int w = 0; w <= W; ++w) xs[w] = b ? funnel(r[w + 1], r[w], 2 * b) : r[w];
-            const uint32_t bp0 = (uint32_t)((sp.pre_pat >> (2 * b)) & 3ull) * 0x55555555u;
-            const uint32_t bp1 = (uint32_t)((sp.pre_pat >> (2 * b + 32)) & 3ull) * 0x55555555u;
-            const uint32_t bs0 = (uint32_t)((sp.suf_pat >> (2 * b)) & 3ull) * 0x55555555u;
-            const uint32_t bs1 = (uint32_t)((sp.suf_pat >> (2 * b + 32)) & 3ull) * 0x55555555u;
             if (p0) {
+                const uint32_t bp = to_vgpr_u((uint32_t)((sp.pre_pat >> (2 * b)) & 3ull) * 0x55555555u);
 #pragma unroll
-                for (int w = 0; w < W; ++w) accP[w] |= xs[w] ^ bp0;
+                for (int w = 0; w < W; ++w) accP[w] |= xs[w] ^ bp;
             }
             if (p1) {
+                const uint32_t bp = to_vgpr_u((uint32_t)((sp.pre_pat >> (2 * b + 32)) & 3ull) * 0x55555555u);
 #pragma unroll
-                for (int w = 0; w < W; ++w) accP[w] |= xs[w + 1] ^ bp1;
+                for (int w = 0; w < W; ++w) accP[w] |= xs[w + 1] ^ bp;
             }
             if (s0) {
+                const uint32_t bp = to_vgpr_u((uint32_t)((sp.suf_pat >> (2 * b)) & 3ull) * 0x55555555u);
 #pragma unroll
-                for (int w = 0; w < W; ++w) accS[w] |= xs[w] ^ bs0;
+                for (int w = 0; w < W; ++w) accS[w] |= xs[w] ^ bp;
             }
             if (s1) {
+                const uint32_t bp = to_vgpr_u((uint32_t)((sp.suf_pat >> (2 * b + 32)) & 3ull) * 0x55555555u);
 #pragma unroll
-                for (int w = 0; w < W; ++w) accS[w] |= xs[w + 1] ^ bs1;
+                for (int w = 0; w < W; ++w) accS[w] |= xs[w + 1] ^ bp;
             }
         }
     }
-    ps = first_hit<W>(accP, n, mp);
-    ss = first_hit<W>(accS, n, ms);
+    uint32_t hP[W], hS[W];
+    scan_candidates<W>(accP, hP);
+    scan_candidates<W>(accS, hS);
+    ps = -1; ss = -1;
+    bool doneP = false, doneS = false;
+    for (;;) {
+        uint32_t cp = 0, cs = 0;
+        if (!doneP) { cp = first_candidate<W>(hP); if (cp + (uint32_t)mp > (uint32_t)n) doneP = true; }     // none, or every later one is further right still
+        if (!doneS) { cs = first_candidate<W>(hS); if (cs + (uint32_t)ms > (uint32_t)n) doneS = true; }
+        if (!__any(!doneP || !doneS)) break;
+        if (!doneP) {
+            if (verify_at<W>(row, (int)cp, sp.pre_pat, mp)) { ps = (int)cp; doneP = true; }
+            else drop_candidate<W>(hP, cp);
+        }
+        if (!doneS) {
+            if (verify_at<W>(row, (int)cs, sp.suf_pat, ms)) { ss = (int)cs; doneS = true; }
+            else drop_candidate<W>(hS, cs);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -147,17 +202,27 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ ro
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const uint64_t n_round = (n_reads + WAVE - 1) / WAVE * WAVE;
     const uint64_t seg0 = (uint64_t)blockIdx.x * bl.seg;
+    // the next trip's row is fetched before this trip's search starts
+    uint32_t x_next[W + 2];
+    int n_next = 0;
+    auto prefetch = [&](uint64_t rr) {
+        if (rr < n_reads) { load_row<W>(rows, rr, x_next); n_next = lens[rr]; }
+        else {
+            n_next = 0;
+#pragma unroll
+            for (int i = 0; i < W + 2; ++i) x_next[i] = 0;
+        }
+    };
+    prefetch((uint64_t)blockIdx.x * kBlock + threadIdx.x);
     for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n_round; r += stride) {
         const bool valid = r < n_reads;
         uint32_t x[W + 2];
-        int n = 0;
-        if (valid) { load_row<W>(rows, r, x); n = lens[r]; }
-        else {
 #pragma unroll
-            for (int i = 0; i < W + 2; ++i) x[i] = 0;
-        }
+        for (int i = 0; i < W + 2; ++i) x[i] = x_next[i];
+        const int n = n_next;
+        prefetch(r + stride);
         int ps, ss;
-        exact_find2<W>(x, n, sp, ps, ss);
+        exact_find2<W>(x, rows + (valid ? r : 0) * W, n, sp, ps, ss);
         int start = ps >= 0 ? ps + (int)sp.pre_len : (sp.align_pre ? (int)kPending : (int)kNone);
         int end = ss >= 0 ? ss : ((sp.align_suf && (sp.independent || start != kNone)) ? (int)kPending : (int)kNone);
         const bool needP = valid && start == kPending;
@@ -208,6 +273,12 @@ __device__ __forceinline__ void dp_lds_fill(DpLds &L, const DpParams &dp) {
     }
 }
 
+__device__ __forceinline__ int32_t to_vgpr(int32_t s) {
+    int32_t v;
+    asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
+
 // one DP column: (Hin,Ein) = column j-1, (Hout,Eout) = column j; pc = profile row of the read base
 template <int M>
 __device__ __forceinline__ void dp_column(const int32_t (&Hin)[M], const int32_t (&Ein)[M], int32_t (&Hout)[M],
@@ -219,12 +290,15 @@ __device__ __forceinline__ void dp_column(const int32_t (&Hin)[M], const int32_t
         const int4 v = reinterpret_cast<const int4 *>(pc)[q];
         pv[4 * q] = v.x; pv[4 * q + 1] = v.y; pv[4 * q + 2] = v.z; pv[4 * q + 3] = v.w;
     }
+    // the four gap constants sit in VGPRs: VALU instructions with an SGPR operand issue at half rate on
+    // gfx950 (scripts/ubench/valu_rate3.hip), and these adds are 4 of the cell's 11 instructions
+    const int32_t e_open = to_vgpr(dp.e_open_k), e_ext = to_vgpr(dp.e_ext_k), f_open = to_vgpr(dp.f_open_k), f_ext = to_vgpr(dp.f_ext_k);
     int32_t hdiag = kV0, hup = kV0, f1 = kNegF;
 #pragma unroll
     for (int i = 0; i < M; ++i) {
         const int32_t hc = Hin[i], ec = Ein[i];
-        const int32_t e = max(hc + dp.e_open_k, ec + dp.e_ext_k) & kClr;
-        const int32_t f = max(hup + dp.f_open_k, f1 + dp.f_ext_k) | (int32_t)(1u << kPrefShift);
+        const int32_t e = max(hc + e_open, ec + e_ext) & kClr;
+        const int32_t f = max(hup + f_open, f1 + f_ext) | (int32_t)(1u << kPrefShift);
         const int32_t d = hdiag + pv[i];
         const int32_t h = max(max(d, f), e) & kClr;
         hdiag = hc;
@@ -431,55 +505,69 @@ __global__ __launch_bounds__(kBlock) void k_dp(const uint32_t *__restrict__ rows
 // columns; clusters further apart than m + kerr have disjoint windows.
 struct Clusters { int ncl, jmin1, jmax1, jmin2, jmax2; };
 
-__device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int n, const DpParams &dp, const uint32_t *s_eq,
+// one Myers column; sc tracks the last adapter row (bit 31) through the horizontal deltas.  Shifts by a
+// constant, and/or/xor/add and v_bitop3 on VGPRs are all full rate; carry-chain adds are not.
+__device__ __forceinline__ void myers_column(uint32_t Eq, uint32_t &Pv, uint32_t &Mv, int &sc) {
+    const uint32_t Xv = Eq | Mv;
+    const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+    uint32_t Ph = Mv | ~(Xh | Pv);
+    uint32_t Mh = Pv & Xh;
+    sc += (int)(Ph >> 31) - (int)(Mh >> 31);
+    Ph <<= 1;
+    Mh <<= 1;
+    Pv = Mh | ~(Xv | Ph);
+    Mv = Ph & Xv;
+}
+
+// s_eq2[16]: entry (b0 | b1<<2) = {Eq[b0], Eq[b1]}: one 8-byte LDS read serves two columns.
+// Every lane of the wave runs the same number of 16-column words (the longest read's); columns past a
+// lane's own read are computed on the row's zero padding and masked out of the detections, so the
+// column loop has no divergent control flow at all.
+__device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int n, const DpParams &dp, const uint2 *s_eq2,
                                            Clusters &cl) {
     uint32_t Pv = dp.pv_init, Mv = 0u;
-    int sc = (int)dp.m;
+    int sc = (int)dp.m - dp.kerr - 1;                  // unit edit distance minus (kerr + 1): negative <=> detected
     const int gap = (int)dp.m + dp.kerr;
     cl.ncl = 0; cl.jmin1 = 0; cl.jmax1 = 0; cl.jmin2 = 0; cl.jmax2 = 0;
     const int nwords = (n + 15) >> 4;
+    int nw_max = nwords;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) nw_max = max(nw_max, __shfl_xor(nw_max, o));
+    nw_max = __builtin_amdgcn_readfirstlane(nw_max);
+    auto eq_pair = [&](uint32_t byte_off) {            // byte_off = entry index * 8
+        return *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(s_eq2) + byte_off);
+    };
+    auto add_run = [&](int jf, int jl) {               // detections jf..jl, all within `gap` of each other
+        if (cl.ncl == 0) { cl.ncl = 1; cl.jmin1 = jf; cl.jmax1 = jl; }
+        else if (cl.ncl == 1) { if (jf - cl.jmax1 > gap) { cl.ncl = 2; cl.jmin2 = jf; cl.jmax2 = jl; } else cl.jmax1 = jl; }
+        else if (cl.ncl == 2) { if (jf - cl.jmax2 > gap) cl.ncl = 3; else cl.jmax2 = jl; }
+    };
     uint32_t word_next = nwords > 0 ? row[0] : 0u;
-    for (int w = 0; w < nwords; ++w) {
+    for (int w = 0; w < nw_max; ++w) {
         uint32_t word = word_next;
-        if (w + 1 < nwords) word_next = row[w + 1];
+        word_next = w + 1 < nwords ? row[w + 1] : 0u;
+        uint32_t det = 0;                              // one bit per column, newest in bit 0
+        uint2 e[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) e[q] = eq_pair(q == 0 ? (word << 3) & 0x78u : (word >> (4 * q - 3)) & 0x78u);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            myers_column(e[q].x, Pv, Mv, sc); det = funnel(det, (uint32_t)sc, 31);
+            myers_column(e[q].y, Pv, Mv, sc); det = funnel(det, (uint32_t)sc, 31);
+        }
+        // bit 15-k <=> column 16w+k+1; only the lane's own columns count
         const int kmax = min(16, n - 16 * w);
-        uint32_t miss = 0;
-        auto eq_of = [&](uint32_t base2) {                 // LDS read of the Eq mask of one base
-            return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_eq) + (base2 << 2));
-        };
-        auto column = [&](uint32_t Eq) {
-            const uint32_t Xv = Eq | Mv;
-            const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-            uint32_t Ph = Mv | ~(Xh | Pv);
-            uint32_t Mh = Pv & Xh;
-            sc += (int)(Ph >> 31) - (int)(Mh >> 31);
-            Ph <<= 1;
-            Mh <<= 1;
-            Pv = Mh | ~(Xv | Ph);
-            Mv = Ph & Xv;
-            miss = (miss << 1) | ((uint32_t)(dp.kerr - sc) >> 31);
-        };
-        // four columns per trip: their Eq masks are read from LDS together, so the dependent chain of
-        // a column waits for LDS once per four columns instead of every column
-        int k = 0;
-        for (; k + 4 <= kmax; k += 4) {
-            const uint32_t e0 = eq_of(word & 3u), e1 = eq_of((word >> 2) & 3u), e2 = eq_of((word >> 4) & 3u), e3 = eq_of((word >> 6) & 3u);
-            word >>= 8;
-            column(e0); column(e1); column(e2); column(e3);
-        }
-        for (; k < kmax; ++k) {
-            const uint32_t e0 = eq_of(word & 3u);
-            word >>= 2;
-            column(e0);
-        }
-        uint32_t det = ~miss & ((1u << kmax) - 1u);     // bit kmax-1-k <=> column 16w+k+1 detected
-        while (det) {
-            const int hb = 31 - __clz((int)det);
-            det &= ~(1u << hb);
-            const int j = 16 * w + (kmax - 1 - hb) + 1;
-            if (cl.ncl == 0) { cl.ncl = 1; cl.jmin1 = j; cl.jmax1 = j; }
-            else if (cl.ncl == 1) { if (j - cl.jmax1 > gap) { cl.ncl = 2; cl.jmin2 = j; cl.jmax2 = j; } else cl.jmax1 = j; }
-            else if (cl.ncl == 2) { if (j - cl.jmax2 > gap) cl.ncl = 3; else cl.jmax2 = j; }
+        det &= kmax > 0 ? (0xFFFFu & ~((1u << (16 - kmax)) - 1u)) : 0u;
+        if (det) {
+            if (gap >= 15) {                           // a word's detections always share a cluster
+                add_run(16 * w + 16 - (31 - __clz((int)det)), 16 * w + 16 - (__ffs((int)det) - 1));
+            } else {
+                while (det) {
+                    const int hb = 31 - __clz((int)det);
+                    det &= ~(1u << hb);
+                    add_run(16 * w + 16 - hb, 16 * w + 16 - hb);
+                }
+            }
         }
     }
 }
@@ -502,8 +590,8 @@ __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ 
                                                    DpParams dp, short2 *__restrict__ spans, BatchLists bl,
                                                    uint64_t *__restrict__ counters) {
     __shared__ uint32_t s_c[5];
-    __shared__ uint32_t s_eq[4];
-    if (threadIdx.x < 4) s_eq[threadIdx.x] = dp.eq_top[threadIdx.x];
+    __shared__ uint2 s_eq2[16];
+    if (threadIdx.x < 16) s_eq2[threadIdx.x] = make_uint2(dp.eq_top[threadIdx.x & 3], dp.eq_top[threadIdx.x >> 2]);
     const uint32_t *list = dp.is_prefix ? bl.listP : bl.listS;
     const uint32_t *cnt = dp.is_prefix ? bl.cntP : bl.cntS;
     uint32_t stat = 0;
@@ -519,7 +607,7 @@ __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ 
             int n = 0;
             if (valid) { r = list[seg0 + t]; n = lens[r]; }
             Clusters cl;
-            myers_scan(rows + (uint64_t)r * W, n, dp, s_eq, cl);
+            myers_scan(rows + (uint64_t)r * W, n, dp, s_eq2, cl);
             const bool any = valid && cl.ncl > 0;
             if (valid && !any) (void)dp_commit(true, r, n, false, 0, dp, spans);
             const int base = (int)dp.m + dp.kerr;
@@ -940,105 +1028,233 @@ __device__ __forceinline__ void agg_flush(Agg &a, const Table &t) {
 // standard genetic code, index = b0 + 4*b1 + 16*b2 (little-endian codon as it sits in the row)
 __constant__ uint8_t c_codon_le[64];
 
-template <int W>
+// The key of one read: region [start,end) of its row, as peptide letters (lib.rs:16-44) or, with
+// skip_translation, as the 2-bit bases themselves (expanded to letters by the host).
+template <int W, bool DNA> struct FinishKey {
+    static constexpr int MAXC = (16 * W) / 3;                    // codons a row can hold
+    static constexpr int ND = DNA ? W : (MAXC + 3) / 4;          // key dwords
+    static constexpr uint32_t kKind = DNA ? kKindPacked : kKindBytes;
+};
+
+// x is consumed (shifted in place).  len = key length in letters / bases, act = the read is counted.
+template <int W, bool DNA>
+__device__ __forceinline__ void finish_key(uint32_t (&x)[W + 2], int start, int end, bool ok, const uint8_t *lut,
+                                           uint32_t (&key)[FinishKey<W, DNA>::ND], uint32_t &len, bool &act) {
+    // shift the row right by `start` bases: word-granular barrel shifter, then bit funnel
+    const uint32_t sh = 2u * (uint32_t)(ok ? start : 0), ws = sh >> 5, bs = sh & 31u;
+#pragma unroll
+    for (int s = 1; s < W; s <<= 1) {
+        const bool take = (ws & (uint32_t)s) != 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const uint32_t from = w + s < W ? x[w + s] : 0u;
+            x[w] = take ? from : x[w];
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w) x[w] = funnel(x[w + 1], x[w], bs);
+    const uint32_t L = ok ? (uint32_t)(end - start) : 0u;
+    if constexpr (DNA) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const int rem = (int)L - 16 * w;
+            const uint32_t mask = rem >= 16 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (2 * rem)) - 1u));
+            key[w] = x[w] & mask;
+        }
+        len = L;
+        act = ok;
+    } else {
+        constexpr int MAXC = FinishKey<W, DNA>::MAXC;
+        const bool tr = ok && (L % 3u) == 0u;                    // lib.rs:17-19
+        const uint32_t nc = tr ? L / 3u : 0u;
+#pragma unroll
+        for (int d = 0; d < FinishKey<W, DNA>::ND; ++d) {
+            uint32_t kd = 0;
+            if (__any((uint32_t)(4 * d) < nc)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = 4 * d + q;
+                    if (c < MAXC) {
+                        const int bit = 6 * c, wi = bit >> 5, bo = bit & 31;
+                        const uint32_t cod = (bo <= 26 ? (x[wi] >> bo) : funnel(x[wi + 1], x[wi], bo)) & 63u;
+                        kd |= (uint32_t)lut[cod] << (8 * q);
+                    }
+                }
+                const int rem = (int)nc - 4 * d;
+                const uint32_t mask = rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (8 * rem)) - 1u));
+                kd &= mask;
+            }
+            key[d] = kd;
+        }
+        len = nc;
+        act = tr;
+    }
+}
+
+// One-shot lookup of a key that is (most often) already in the table: hash, one slot line, compare.
+// Anything else - empty slot, another key in the slot, a key still being published, a LONG key - is a
+// miss here and goes to the workgroup's slow list, where table_find_or_insert runs with full waves.
+struct FastProbe {
+    uint32_t slot;
+    uint64_t w0want;
+    uint32_t kin[kInlineDwords];
+    bool can;
+};
+template <int ND>
+__device__ __forceinline__ void fast_prepare(const Table &t, const uint32_t (&key)[ND], uint32_t kind, uint32_t len, bool act, FastProbe &p) {
+    const uint32_t nd = key_dwords(kind, len);
+    const uint32_t meta = len | (kind << 16);
+    Hash h;
+    hash_init(h, meta);
+    const RegKey<ND> rk{key};
+    rk.each(nd, [&](uint32_t, uint32_t v) { hash_step(h, v); });
+    hash_fin(h);
+    p.can = act && nd <= (uint32_t)kInlineDwords;
+    p.w0want = (uint64_t)h.h2 | ((uint64_t)meta << 32) | kW0Ready;
+    p.slot = h.h1 & t.slot_mask;
+    rk.head(nd, p.kin);
+}
+__device__ __forceinline__ bool fast_check(const FastProbe &p, const uint4 &l0, const uint4 &l1, const uint4 &l2, const uint4 &l3) {
+    const uint64_t w0 = (uint64_t)l0.x | ((uint64_t)l0.y << 32);
+    const uint32_t diff = (l0.z ^ p.kin[0]) | (l0.w ^ p.kin[1]) | (l1.x ^ p.kin[2]) | (l1.y ^ p.kin[3]) | (l1.z ^ p.kin[4]) | (l1.w ^ p.kin[5]) |
+                          (l2.x ^ p.kin[6]) | (l2.y ^ p.kin[7]) | (l2.z ^ p.kin[8]) | (l2.w ^ p.kin[9]) | (l3.x ^ p.kin[10]) | (l3.y ^ p.kin[11]) |
+                          (l3.z ^ p.kin[12]) | (l3.w ^ p.kin[13]);
+    return p.can && w0 == p.w0want && diff == 0u;
+}
+// two independent slot lines in flight at once
+__device__ __forceinline__ void slot_load2(const uint4 *p, const uint4 *q, uint4 &a, uint4 &b, uint4 &c, uint4 &d,
+                                           uint4 &e, uint4 &f, uint4 &g, uint4 &h) {
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
+                 "global_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %8, off offset:32 sc1\n\t"
+                 "global_load_dwordx4 %3, %8, off offset:48 sc1\n\t"
+                 "global_load_dwordx4 %4, %9, off sc1\n\t"
+                 "global_load_dwordx4 %5, %9, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %6, %9, off offset:32 sc1\n\t"
+                 "global_load_dwordx4 %7, %9, off offset:48 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e), "=&v"(f), "=&v"(g), "=&v"(h) : "v"(p), "v"(q) : "memory");
+}
+
+// U reads per lane and trip (their slot lines are fetched together).  Rows and spans of the next trip are
+// prefetched before the current keys go to the table.  Reads whose key was not found by the one-shot
+// lookup are queued per wave in LDS and handled 64 at a time by table_find_or_insert, so the insert
+// protocol's extra round trips are paid by full waves instead of by every wave that holds one new key.
+constexpr int kSlowCap = 192;
+template <int W, int U, bool DNA>
 __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens,
-                                                   uint64_t n_reads, const short2 *__restrict__ spans,
-                                                   uint32_t skip_translation, Table t) {
-    constexpr int MAXC = (16 * W) / 3;            // codons a row can hold
-    constexpr int NDA = (MAXC + 3) / 4;           // peptide key dwords
+                                                   uint64_t n_reads, const short2 *__restrict__ spans, Table t) {
+    using FK = FinishKey<W, DNA>;
+    constexpr int ND = FK::ND;
     __shared__ uint8_t lut[64];
     __shared__ Agg agg;
     __shared__ BlockTable bt;
     __shared__ uint32_t s_stat[2];
+    __shared__ uint32_t s_slow[kBlock / WAVE][kSlowCap];
     if (threadIdx.x < 64) lut[threadIdx.x] = c_codon_le[threadIdx.x];
     if (threadIdx.x < 2) s_stat[threadIdx.x] = 0;
     agg_init(agg);
     block_table_begin(bt, t);
     __syncthreads();
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    const uint64_t n_round = (n_reads + WAVE - 1) / WAVE * WAVE;
-    // The kernel is latency bound (span load -> row load -> table probe -> insert are dependent round
-    // trips), so the span and the row of the NEXT iteration are fetched before the current read goes to
-    // the table; rows are fetched unconditionally to keep the two loads independent.
-    short2 sp_next = make_short2(kNone, kNone);
-    uint32_t x_next[W + 2];
-    auto prefetch = [&](uint64_t rr) {
-        if (rr < n_reads) { sp_next = spans[rr]; load_row<W>(rows, rr, x_next); }
+    const uint32_t lane = lane_id();
+    uint32_t *slow = s_slow[threadIdx.x / WAVE];
+    uint32_t nslow = 0;                           // wave-uniform
+    const uint64_t gstride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t n_trips = (n_reads + gstride * U - 1) / (gstride * U);
+
+    short2 sp_next[U];
+    uint32_t x_next[U][W + 2];
+    auto prefetch = [&](int u, uint64_t rr) {
+        if (rr < n_reads) { sp_next[u] = spans[rr]; load_row<W>(rows, rr, x_next[u]); }
         else {
-            sp_next = make_short2(kNone, kNone);
+            sp_next[u] = make_short2(kNone, kNone);
 #pragma unroll
-            for (int i = 0; i < W + 2; ++i) x_next[i] = 0;
+            for (int i = 0; i < W + 2; ++i) x_next[u][i] = 0;
         }
     };
-    prefetch((uint64_t)blockIdx.x * kBlock + threadIdx.x);
-    for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n_round; r += stride) {
-        const int start = sp_next.x, end = sp_next.y;
-        const bool ok = start >= 0 && end >= 0 && start < end;      // lib.rs:288
-        uint32_t x[W + 2];
 #pragma unroll
-        for (int i = 0; i < W + 2; ++i) x[i] = x_next[i];
-        prefetch(r + stride);
-        wave_count_lds(&s_stat[0], ok);
-        if (!__any(ok)) continue;
-        // shift the row right by `start` bases: word-granular barrel shifter, then bit funnel
-        const uint32_t sh = 2u * (uint32_t)start, ws = sh >> 5, bs = sh & 31u;
+    for (int u = 0; u < U; ++u) prefetch(u, tid + (uint64_t)u * gstride);
+
+    for (uint64_t trip = 0; trip <= n_trips; ++trip) {
+        const bool last = trip == n_trips;        // the extra trip only drains the slow list
+        if (!last) {
+            uint32_t x[U][W + 2];
+            int start[U], end[U];
+            bool ok[U];
+            uint64_t r[U];
+            bool any_ok = false;
 #pragma unroll
-        for (int s = 1; s < W; s <<= 1) {
-            const bool take = (ws & (uint32_t)s) != 0;
+            for (int u = 0; u < U; ++u) {
+                r[u] = tid + (trip * U + (uint64_t)u) * gstride;
+                start[u] = sp_next[u].x; end[u] = sp_next[u].y;
+                ok[u] = start[u] >= 0 && end[u] >= 0 && start[u] < end[u];      // lib.rs:288
 #pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const uint32_t from = w + s < W ? x[w + s] : 0u;
-                x[w] = take ? from : x[w];
+                for (int i = 0; i < W + 2; ++i) x[u][i] = x_next[u][i];
+                any_ok = any_ok || ok[u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) prefetch(u, r[u] + (uint64_t)U * gstride);
+            if (__any(any_ok)) {
+                uint32_t key[U][ND];
+                uint32_t len[U];
+                bool act[U];
+                FastProbe fp[U];
+                uint32_t n_ok = 0, n_act = 0;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    finish_key<W, DNA>(x[u], start[u], end[u], ok[u], lut, key[u], len[u], act[u]);
+                    fast_prepare<ND>(t, key[u], FK::kKind, len[u], act[u], fp[u]);
+                    n_ok += (uint32_t)__popcll(__ballot(ok[u]));
+                    n_act += (uint32_t)__popcll(__ballot(act[u]));
+                }
+                if (lane == 0) { atomicAdd(&s_stat[0], n_ok); atomicAdd(&s_stat[1], n_act); }
+                bool found[U];
+                if constexpr (U == 2) {
+                    uint4 a, b, c, d, e, f, g, h;
+                    slot_load2(t.slots + (uint64_t)fp[0].slot * 4, t.slots + (uint64_t)fp[1].slot * 4, a, b, c, d, e, f, g, h);
+                    found[0] = fast_check(fp[0], a, b, c, d);
+                    found[1] = fast_check(fp[1], e, f, g, h);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        uint4 a, b, c, d;
+                        slot_load(t.slots + (uint64_t)fp[u].slot * 4, a, b, c, d);
+                        found[u] = fast_check(fp[u], a, b, c, d);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (found[u]) agg_add(agg, t, fp[u].slot);
+                    const bool miss = act[u] && !found[u];
+                    const uint64_t m = __ballot(miss);
+                    if (miss) slow[nslow + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r[u];
+                    nslow += (uint32_t)__popcll(m);
+                    // capacity: < 64 queued before a trip, at most 64 more per read of the trip
+                }
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        while (nslow >= (last ? 1u : (uint32_t)WAVE)) {
+            const uint32_t cnt = nslow < (uint32_t)WAVE ? nslow : (uint32_t)WAVE;
+            const uint32_t base = nslow - cnt;
+            const bool mine = lane < cnt;
+            const uint64_t rr = mine ? (uint64_t)((volatile uint32_t *)slow)[base + lane] : 0ull;
+            uint32_t xs[W + 2];
+            short2 sp = make_short2(kNone, kNone);
+            if (mine) { sp = spans[rr]; load_row<W>(rows, rr, xs); }
+            else {
 #pragma unroll
-        for (int w = 0; w < W; ++w) x[w] = funnel(x[w + 1], x[w], bs);
-        const uint32_t L = ok ? (uint32_t)(end - start) : 0u;
-        if (skip_translation & 1u) {
-            // key = the region itself, 2 bits per base (expanded to letters by the host)
-            uint32_t key[W];
-#pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const int rem = (int)L - 16 * w;
-                const uint32_t mask = rem >= 16 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (2 * rem)) - 1u));
-                key[w] = x[w] & mask;
+                for (int i = 0; i < W + 2; ++i) xs[i] = 0;
             }
-            wave_count_lds(&s_stat[1], ok);
-            agg_add(agg, t, table_find_or_insert(t, bt, RegKey<W>{key}, kKindPacked, L, ok));
-        } else {
-            const bool tr = ok && (L % 3u) == 0u;                    // lib.rs:17-19
-            const uint32_t nc = tr ? L / 3u : 0u;
-            uint32_t key[NDA];
-#pragma unroll
-            for (int d = 0; d < NDA; ++d) {
-                uint32_t kd = 0;
-                if (__any((uint32_t)(4 * d) < nc)) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int c = 4 * d + q;
-                        if (c < MAXC) {
-                            const int bit = 6 * c, wi = bit >> 5, bo = bit & 31;
-                            const uint32_t cod = (bo <= 26 ? (x[wi] >> bo) : funnel(x[wi + 1], x[wi], bo)) & 63u;
-                            kd |= (uint32_t)lut[cod] << (8 * q);
-                        }
-                    }
-                    const int rem = (int)nc - 4 * d;
-                    const uint32_t mask = rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << (8 * rem)) - 1u));
-                    kd &= mask;
-                }
-                key[d] = kd;
-            }
-            wave_count_lds(&s_stat[1], tr);
-            if (skip_translation & 0x100u) {            // profiling aid: hash only, no table traffic
-                uint32_t acc = 0;
-#pragma unroll
-                for (int d = 0; d < NDA; ++d) acc ^= key[d];
-                if (acc == 0x12345678u && tr) atomicAdd(&s_stat[0], 1u);
-            } else {
-                const uint32_t slot = table_find_or_insert(t, bt, RegKey<NDA>{key}, kKindBytes, nc, tr);
-                if (!(skip_translation & 0x200u)) agg_add(agg, t, slot);
-                else if (slot == 0x7FFFFFFFu) atomicAdd(&s_stat[0], 1u);
-            }
+            const bool oks = mine && sp.x >= 0 && sp.y >= 0 && sp.x < sp.y;
+            uint32_t ks[ND];
+            uint32_t ls;
+            bool as;
+            finish_key<W, DNA>(xs, sp.x, sp.y, oks, lut, ks, ls, as);
+            agg_add(agg, t, table_find_or_insert(t, bt, RegKey<ND>{ks}, FK::kKind, ls, as));
+            nslow = base;
+            __builtin_amdgcn_wave_barrier();
         }
     }
     __syncthreads();
@@ -1405,24 +1621,31 @@ hipError_t launch_dp_window(hipStream_t s, int cls, int W, const uint32_t *rows,
 hipError_t launch_filter(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
                          BatchLists bl, uint64_t *counters) {
     if (bl.grid == 0) return hipSuccess;
-    const int g = (int)(bl.grid < 1024u ? bl.grid : 1024u);
+    const int g = (int)bl.grid;                       // one workgroup per list segment (<= kMaxGrid)
     hipLaunchKernelGGL(k_filter, dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, counters);
     return hipGetLastError();
 }
 
 hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n, const short2 *spans,
-                         uint32_t skip_translation, Table t) {
+                         bool skip_translation, Table t) {
     if (n == 0) return hipSuccess;
+    if (n >> 32) return hipErrorInvalidValue;         // read indices are 32-bit in the work lists
     hipError_t e = ensure_lut();
     if (e != hipSuccess) return e;
     static const int per_cu = [] { const char *v = getenv("VFIND_FINISH_BLOCKS_PER_CU"); const int x = v ? atoi(v) : 8; return x >= 1 && x <= 8 ? x : 8; }();
     const int g = grid_for(n, per_cu);
+#define VF_FINISH(WW, UU)                                                                                              \
+    do {                                                                                                               \
+        if (skip_translation) hipLaunchKernelGGL((k_finish<WW, UU, true>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t); \
+        else hipLaunchKernelGGL((k_finish<WW, UU, false>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t);               \
+    } while (0)
     switch (W) {
-    case 10: hipLaunchKernelGGL(k_finish<10>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, skip_translation, t); break;
-    case 20: hipLaunchKernelGGL(k_finish<20>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, skip_translation, t); break;
-    case 40: hipLaunchKernelGGL(k_finish<40>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, skip_translation, t); break;
+    case 10: VF_FINISH(10, 2); break;
+    case 20: VF_FINISH(20, 1); break;
+    case 40: VF_FINISH(40, 1); break;
     default: return hipErrorInvalidValue;
     }
+#undef VF_FINISH
     return hipGetLastError();
 }
 
