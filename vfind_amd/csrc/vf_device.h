@@ -80,6 +80,7 @@ enum Counter : int {        // uint64 counters[] in device memory
 };
 constexpr int kTableCounters = 4;       // C_ARENA_TOP..C_KEY_DWORDS are reset with the table
 
+constexpr int kXcds = 8;                // MI355X: 8 XCDs, each with its own L2 (count arrays are per XCD)
 constexpr uint32_t kChunk = 1024;       // dwords of key arena a workgroup takes per refill (arena_alloc)
 constexpr uint32_t kChunkRows = 21;     // chunk-state rows: 16 batch streams, the main stream, 4 resident lanes
 
@@ -87,7 +88,7 @@ struct Table {
     unsigned long long *chunk_state;  // [kChunkRows][kMaxGrid] workgroup arena chunks (see arena_alloc)
     uint32_t chunk_row;               // row of the launching stream
     uint4 *slots;                     // 4 x uint4 per slot
-    uint64_t *counts;                 // one per slot, apart from the slot lines
+    uint64_t *counts;                 // [kXcds][slots]: one count per slot and XCD, apart from the slot lines
     uint32_t *arena;                  // long keys only
     uint64_t *counters;
     uint32_t slot_mask;

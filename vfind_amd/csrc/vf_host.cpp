@@ -331,7 +331,7 @@ static void fill_dp(DpParams &d, const std::string &ad, int64_t T, const vf_ctx 
 // ------------------------------------------------------------------------------------------------
 static int table_clear_locked(vf_ctx *c, bool all_counters = false) {
     HIP_TRY(hipMemsetAsync(c->t_slots.p, 0, c->table_slots * 64, c->main_stream));
-    HIP_TRY(hipMemsetAsync(c->t_counts.p, 0, c->table_slots * sizeof(uint64_t), c->main_stream));
+    HIP_TRY(hipMemsetAsync(c->t_counts.p, 0, c->table_slots * kXcds * sizeof(uint64_t), c->main_stream));
     HIP_TRY(hipMemsetAsync(c->t_chunks.p, 0, (size_t)kChunkRows * kMaxGrid * sizeof(unsigned long long), c->main_stream));
     // arena top, entry count and error bits belong to the table; the read statistics do not
     HIP_TRY(hipMemsetAsync(c->t_counters.p, 0, (all_counters ? (size_t)C_NUM : (size_t)kTableCounters) * sizeof(uint64_t), c->main_stream));
@@ -418,7 +418,7 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     c->table_slots = pow2;
     c->arena_dwords = (p->arena_bytes ? p->arena_bytes : (1ull << 30)) / 4;
     if ((rc = c->t_slots.ensure(c->table_slots * 4))) return rc;
-    if ((rc = c->t_counts.ensure(c->table_slots))) return rc;
+    if ((rc = c->t_counts.ensure(c->table_slots * kXcds))) return rc;
     if ((rc = c->t_arena.ensure(c->arena_dwords))) return rc;
     if ((rc = c->t_counters.ensure(C_NUM))) return rc;
     if ((rc = c->t_chunks.ensure((size_t)kChunkRows * kMaxGrid))) return rc;
@@ -547,9 +547,9 @@ static int table_grow_locked(vf_ctx *c, bool use_unenqueued, uint64_t extra) {
         if (new_slots > (1ull << 32)) return fail(VF_ECAPACITY, "device count table cannot grow beyond 2^32 slots");
         DevBuf<uint4> n_slots; DevBuf<uint64_t> n_counts;
         if ((rc = n_slots.ensure(new_slots * 4))) return rc;
-        if ((rc = n_counts.ensure(new_slots))) { n_slots.release(); return rc; }
+        if ((rc = n_counts.ensure(new_slots * kXcds))) { n_slots.release(); return rc; }
         HIP_TRY(hipMemsetAsync(n_slots.p, 0, new_slots * 64, c->main_stream));
-        HIP_TRY(hipMemsetAsync(n_counts.p, 0, new_slots * sizeof(uint64_t), c->main_stream));
+        HIP_TRY(hipMemsetAsync(n_counts.p, 0, new_slots * kXcds * sizeof(uint64_t), c->main_stream));
         HIP_TRY(hipMemsetAsync(c->t_counters.p + C_ENTRIES, 0, sizeof(uint64_t), c->main_stream));     // recounted by the re-insert
         HIP_TRY(hipMemsetAsync(c->t_counters.p + C_KEY_DWORDS, 0, sizeof(uint64_t), c->main_stream));
         Table to = c->tab;

@@ -522,9 +522,13 @@ __device__ __forceinline__ void myers_column(uint32_t Eq, uint32_t &Pv, uint32_t
 // s_eq2[16]: entry (b0 | b1<<2) = {Eq[b0], Eq[b1]}: one 8-byte LDS read serves two columns.
 // Every lane of the wave runs the same number of 16-column words (the longest read's); columns past a
 // lane's own read are computed on the row's zero padding and masked out of the detections, so the
-// column loop has no divergent control flow at all.
+// column loop has no divergent control flow at all.  The row is held in registers ten words (one
+// 40-byte chunk) at a time and the next chunk is fetched while the current one is scanned: a load per
+// word inside the loop made every word wait for global memory (59 % of the kernel's wave cycles).
+template <int W>
 __device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int n, const DpParams &dp, const uint2 *s_eq2,
                                            Clusters &cl) {
+    constexpr int CW = 10;                             // words per chunk
     uint32_t Pv = dp.pv_init, Mv = 0u;
     int sc = (int)dp.m - dp.kerr - 1;                  // unit edit distance minus (kerr + 1): negative <=> detected
     const int gap = (int)dp.m + dp.kerr;
@@ -542,30 +546,49 @@ __device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int
         else if (cl.ncl == 1) { if (jf - cl.jmax1 > gap) { cl.ncl = 2; cl.jmin2 = jf; cl.jmax2 = jl; } else cl.jmax1 = jl; }
         else if (cl.ncl == 2) { if (jf - cl.jmax2 > gap) cl.ncl = 3; else cl.jmax2 = jl; }
     };
-    uint32_t word_next = nwords > 0 ? row[0] : 0u;
-    for (int w = 0; w < nw_max; ++w) {
-        uint32_t word = word_next;
-        word_next = w + 1 < nwords ? row[w + 1] : 0u;
-        uint32_t det = 0;                              // one bit per column, newest in bit 0
-        uint2 e[8];
+    uint32_t xn[CW];
+    auto fetch = [&](int c) {                          // chunk c of this lane's row (zeros past its own words)
+        const uint2 *p = reinterpret_cast<const uint2 *>(row + c * CW);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) e[q] = eq_pair(q == 0 ? (word << 3) & 0x78u : (word >> (4 * q - 3)) & 0x78u);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            myers_column(e[q].x, Pv, Mv, sc); det = funnel(det, (uint32_t)sc, 31);
-            myers_column(e[q].y, Pv, Mv, sc); det = funnel(det, (uint32_t)sc, 31);
+        for (int i = 0; i < CW / 2; ++i) {
+            uint2 v = make_uint2(0u, 0u);
+            if (c * CW + 2 * i < nwords) v = p[i];     // rows are W = 10 k words: a pair never straddles the row end
+            xn[2 * i] = v.x; xn[2 * i + 1] = v.y;
         }
-        // bit 15-k <=> column 16w+k+1; only the lane's own columns count
-        const int kmax = min(16, n - 16 * w);
-        det &= kmax > 0 ? (0xFFFFu & ~((1u << (16 - kmax)) - 1u)) : 0u;
-        if (det) {
-            if (gap >= 15) {                           // a word's detections always share a cluster
-                add_run(16 * w + 16 - (31 - __clz((int)det)), 16 * w + 16 - (__ffs((int)det) - 1));
-            } else {
-                while (det) {
-                    const int hb = 31 - __clz((int)det);
-                    det &= ~(1u << hb);
-                    add_run(16 * w + 16 - hb, 16 * w + 16 - hb);
+    };
+    fetch(0);
+    for (int c = 0; c * CW < nw_max; ++c) {
+        uint32_t x[CW];
+#pragma unroll
+        for (int i = 0; i < CW; ++i) x[i] = xn[i];
+        if ((c + 1) * CW < nw_max && W > CW) fetch(c + 1);
+#pragma unroll
+        for (int wi = 0; wi < CW; ++wi) {
+            const int w = c * CW + wi;
+            if (w < nw_max) {                          // wave-uniform
+                const uint32_t word = x[wi];
+                uint32_t det = 0;                      // one bit per column, newest in bit 0
+                uint2 e[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) e[q] = eq_pair(q == 0 ? (word << 3) & 0x78u : (word >> (4 * q - 3)) & 0x78u);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    myers_column(e[q].x, Pv, Mv, sc); det = funnel(det, (uint32_t)sc, 31);
+                    myers_column(e[q].y, Pv, Mv, sc); det = funnel(det, (uint32_t)sc, 31);
+                }
+                // bit 15-k <=> column 16w+k+1; only the lane's own columns count
+                const int kmax = min(16, n - 16 * w);
+                det &= kmax > 0 ? (0xFFFFu & ~((1u << (16 - kmax)) - 1u)) : 0u;
+                if (det) {
+                    if (gap >= 15) {                   // a word's detections always share a cluster
+                        add_run(16 * w + 16 - (31 - __clz((int)det)), 16 * w + 16 - (__ffs((int)det) - 1));
+                    } else {
+                        while (det) {
+                            const int hb = 31 - __clz((int)det);
+                            det &= ~(1u << hb);
+                            add_run(16 * w + 16 - hb, 16 * w + 16 - hb);
+                        }
+                    }
                 }
             }
         }
@@ -586,7 +609,8 @@ __device__ __forceinline__ int window_class(const Clusters &cl, int a1, int a2, 
     return 4;
 }
 
-__global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
+template <int W>
+__global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens,
                                                    DpParams dp, short2 *__restrict__ spans, BatchLists bl,
                                                    uint64_t *__restrict__ counters) {
     __shared__ uint32_t s_c[5];
@@ -607,7 +631,7 @@ __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ 
             int n = 0;
             if (valid) { r = list[seg0 + t]; n = lens[r]; }
             Clusters cl;
-            myers_scan(rows + (uint64_t)r * W, n, dp, s_eq2, cl);
+            myers_scan<W>(rows + (uint64_t)r * W, n, dp, s_eq2, cl);
             const bool any = valid && cl.ncl > 0;
             if (valid && !any) (void)dp_commit(true, r, n, false, 0, dp, spans);
             const int base = (int)dp.m + dp.kerr;
@@ -655,6 +679,14 @@ __device__ __forceinline__ void dp_window_run(int32_t (&HA)[M], int32_t (&EA)[M]
     q0 = funnel(q1, q0, ph); q1 = funnel(q2, q1, ph); q2 = funnel(q3, q2, ph); q3 = funnel(q4, q3, ph); q4 >>= ph;
     int32_t hl;
     const int wlen = b - a;
+#ifdef VF_DP_INPLACE
+    (void)HB; (void)EB;
+    for (int t = 0; t < wlen; ++t) {
+        dp_column<M>(HA, EA, HA, EA, L.prof + (q0 & 3u) * kProfStride, dp, hl);
+        dp_track(hl, best_s, best_v);
+        q0 = funnel(q1, q0, 2); q1 = funnel(q2, q1, 2); q2 = funnel(q3, q2, 2); q3 = funnel(q4, q3, 2); q4 >>= 2;
+    }
+#else
     int t = 0;
     for (; t + 2 <= wlen; t += 2) {
         dp_column<M>(HA, EA, HB, EB, L.prof + (q0 & 3u) * kProfStride, dp, hl);
@@ -669,6 +701,7 @@ __device__ __forceinline__ void dp_window_run(int32_t (&HA)[M], int32_t (&EA)[M]
 #pragma unroll
         for (int i = 0; i < M; ++i) { HA[i] = HB[i]; EA[i] = EB[i]; }
     }
+#endif
 }
 
 // one window, or two disjoint windows left to right (the cells between them are off all accepting
@@ -816,8 +849,24 @@ __device__ __forceinline__ void slot_store_nowait(uint4 *p, u32x4 a, u32x4 b, u3
                  "global_store_dwordx4 %0, %4, off offset:48 sc1"
                  :: "v"(p), "v"(a), "v"(b), "v"(c), "v"(d) : "memory");
 }
-__device__ __forceinline__ unsigned long long *slot_count(const Table &t, uint32_t slot) {
-    return reinterpret_cast<unsigned long long *>(t.counts) + slot;
+// Counts: one u64 array per XCD (t.counts[xcd][slot]).  A count is bumped with an atomic that executes in
+// the issuing XCD's own L2 (no sc1): all CUs of an XCD share that L2, and no other XCD ever touches this
+// copy, so the add is coherent without going to the memory side - device-scope atomics do, and ~3 M of
+// them per 10 M reads cost more than everything else in k_finish together (measured: 0.45 ms of 0.55).
+// Readers (export, rehash) run in later kernels and sum the kXcds copies.
+__device__ __forceinline__ uint32_t xcc_id() {
+    // HW_REG_XCC_ID (id 20), bits [3:0]: s_getreg_b32 simm16 = (size-1)<<11 | offset<<6 | id
+    return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & (uint32_t)(kXcds - 1);
+}
+__device__ __forceinline__ void count_add(const Table &t, uint32_t xcc, uint32_t slot, unsigned long long v) {
+    unsigned long long *p = reinterpret_cast<unsigned long long *>(t.counts) + (uint64_t)xcc * ((uint64_t)t.slot_mask + 1ull) + slot;
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint64_t count_get(const Table &t, uint64_t slot) {
+    uint64_t v = 0;
+#pragma unroll
+    for (int x = 0; x < kXcds; ++x) v += t.counts[(uint64_t)x * ((uint64_t)t.slot_mask + 1ull) + slot];
+    return v;
 }
 
 // ---- workgroup-local state: arena chunks for LONG keys, insert counters --------------------------
@@ -993,7 +1042,7 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
 template <class K>
 __device__ __forceinline__ void table_add(const Table &t, BlockTable &bt, const K &key, uint32_t kind, uint32_t len, uint64_t cnt, bool active) {
     const uint32_t slot = table_find_or_insert(t, bt, key, kind, len, active);
-    if (slot != kNoSlot) atomicAdd(slot_count(t, slot), (unsigned long long)cnt);
+    if (slot != kNoSlot) count_add(t, xcc_id(), slot, (unsigned long long)cnt);
 }
 
 // Workgroup-level count aggregation: a small LDS table keyed by slot index collects the +1s of a
@@ -1009,17 +1058,17 @@ struct Agg {
 __device__ __forceinline__ void agg_init(Agg &a) {
     for (int i = threadIdx.x; i < kAggSize; i += kBlock) { a.slot[i] = kNoSlot; a.cnt[i] = 0; }
 }
-__device__ __forceinline__ void agg_add(Agg &a, const Table &t, uint32_t slot) {
+__device__ __forceinline__ void agg_add(Agg &a, const Table &t, uint32_t xcc, uint32_t slot) {
     if (slot == kNoSlot) return;
     const uint32_t i = (slot * 0x9E3779B1u) >> 22;                 // 10 bits
     uint32_t cur = *(volatile uint32_t *)&a.slot[i];
     if (cur == kNoSlot) { cur = atomicCAS(&a.slot[i], kNoSlot, slot); if (cur == kNoSlot) cur = slot; }
     if (cur == slot) atomicAdd(&a.cnt[i], 1u);
-    else atomicAdd(slot_count(t, slot), 1ull);
+    else count_add(t, xcc, slot, 1ull);
 }
-__device__ __forceinline__ void agg_flush(Agg &a, const Table &t) {
+__device__ __forceinline__ void agg_flush(Agg &a, const Table &t, uint32_t xcc) {
     for (int i = threadIdx.x; i < kAggSize; i += kBlock)
-        if (a.slot[i] != kNoSlot && a.cnt[i]) atomicAdd(slot_count(t, a.slot[i]), (unsigned long long)a.cnt[i]);
+        if (a.slot[i] != kNoSlot && a.cnt[i]) count_add(t, xcc, a.slot[i], (unsigned long long)a.cnt[i]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1141,7 +1190,7 @@ __device__ __forceinline__ void slot_load2(const uint4 *p, const uint4 *q, uint4
 // lookup are queued per wave in LDS and handled 64 at a time by table_find_or_insert, so the insert
 // protocol's extra round trips are paid by full waves instead of by every wave that holds one new key.
 constexpr int kSlowCap = 192;
-template <int W, int U, bool DNA>
+template <int W, int U, bool DNA, int DBG = 0>
 __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens,
                                                    uint64_t n_reads, const short2 *__restrict__ spans, Table t) {
     using FK = FinishKey<W, DNA>;
@@ -1157,6 +1206,7 @@ __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ 
     block_table_begin(bt, t);
     __syncthreads();
     const uint32_t lane = lane_id();
+    const uint32_t xcc = xcc_id();
     uint32_t *slow = s_slow[threadIdx.x / WAVE];
     uint32_t nslow = 0;                           // wave-uniform
     const uint64_t gstride = (uint64_t)gridDim.x * kBlock;
@@ -1166,7 +1216,13 @@ __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ 
     short2 sp_next[U];
     uint32_t x_next[U][W + 2];
     auto prefetch = [&](int u, uint64_t rr) {
-        if (rr < n_reads) { sp_next[u] = spans[rr]; load_row<W>(rows, rr, x_next[u]); }
+        if (rr < n_reads) {
+            sp_next[u] = spans[rr];
+            if constexpr (DBG == 2) {
+#pragma unroll
+                for (int i = 0; i < W + 2; ++i) x_next[u][i] = (uint32_t)rr * 2654435761u + i;
+            } else load_row<W>(rows, rr, x_next[u]);
+        }
         else {
             sp_next[u] = make_short2(kNone, kNone);
 #pragma unroll
@@ -1212,9 +1268,12 @@ __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ 
                 bool found[U];
                 if constexpr (U == 2) {
                     uint4 a, b, c, d, e, f, g, h;
+                    if constexpr (DBG == 1 || DBG == 3) { found[0] = fp[0].can; found[1] = fp[1].can; }
+                    else {
                     slot_load2(t.slots + (uint64_t)fp[0].slot * 4, t.slots + (uint64_t)fp[1].slot * 4, a, b, c, d, e, f, g, h);
                     found[0] = fast_check(fp[0], a, b, c, d);
                     found[1] = fast_check(fp[1], e, f, g, h);
+                    }
                 } else {
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
@@ -1225,7 +1284,7 @@ __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ 
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if (found[u]) agg_add(agg, t, fp[u].slot);
+                    if (found[u] && DBG != 3 && DBG != 4) agg_add(agg, t, xcc, fp[u].slot);
                     const bool miss = act[u] && !found[u];
                     const uint64_t m = __ballot(miss);
                     if (miss) slow[nslow + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r[u];
@@ -1252,13 +1311,13 @@ __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ 
             uint32_t ls;
             bool as;
             finish_key<W, DNA>(xs, sp.x, sp.y, oks, lut, ks, ls, as);
-            agg_add(agg, t, table_find_or_insert(t, bt, RegKey<ND>{ks}, FK::kKind, ls, as));
+            agg_add(agg, t, xcc, table_find_or_insert(t, bt, RegKey<ND>{ks}, FK::kKind, ls, as));
             nslow = base;
             __builtin_amdgcn_wave_barrier();
         }
     }
     __syncthreads();
-    agg_flush(agg, t);
+    agg_flush(agg, t, xcc);
     block_table_end(bt, t);
     if (threadIdx.x == 0) {
         if (s_stat[0]) atomicAdd((unsigned long long *)&t.counters[C_ACCEPTED], (unsigned long long)s_stat[0]);
@@ -1468,7 +1527,7 @@ __global__ __launch_bounds__(kBlock) void k_export(Table t, uint64_t *__restrict
             const uint64_t e = base_e + __popcll(m & ((1ull << lane_id()) - 1ull));
             const uint64_t ko = base_k + (incl - nd);
             out_refs[e] = (ko << 24) | kRefValid | (uint64_t)meta;
-            out_counts[e] = t.counts[s];
+            out_counts[e] = count_get(t, s);
             if (w0 & kW0Long) {
                 const uint64_t off = (uint64_t)l0.z | ((uint64_t)l0.w << 32);
                 for (uint32_t d = 0; d < nd; ++d) out_arena[ko + d] = t.arena[off + d];
@@ -1517,7 +1576,7 @@ __global__ __launch_bounds__(kBlock) void k_rehash(Table from, Table to) {
             w0 = (uint64_t)l0.x | ((uint64_t)l0.y << 32);
             live = (w0 & kW0Ready) && !(w0 & kW0Ovf);
             if (live) {
-                cnt = from.counts[s];
+                cnt = count_get(from, s);
                 off = (uint64_t)l0.z | ((uint64_t)l0.w << 32);
                 kp = (w0 & kW0Long) ? from.arena + off : reinterpret_cast<const uint32_t *>(sp) + 2;
             }
@@ -1591,7 +1650,8 @@ static hipError_t launch_dp_any(hipStream_t s, int which, int W, const uint32_t 
                                 short2 *spans, BatchLists bl, const uint32_t *list, const uint32_t *cnt, uint32_t count_stat,
                                 uint64_t *counters) {
     if (bl.grid == 0) return hipSuccess;
-    const int g = (int)(bl.grid < 1024u ? bl.grid : 1024u);
+    static const uint32_t g_max = [] { const char *v = getenv("VFIND_DP_GRID"); const int x = v ? atoi(v) : 1024; return (uint32_t)(x >= 64 && x <= (int)kMaxGrid ? x : 1024); }();
+    const int g = (int)(bl.grid < g_max ? bl.grid : g_max);
 #define VF_DP_CASE(M) case M: launch_dp_m<M>(s, which, g, rows, lens, W, dp, spans, bl, list, cnt, count_stat, counters); break;
     switch (dp.m) {
         VF_DP_CASE(1) VF_DP_CASE(2) VF_DP_CASE(3) VF_DP_CASE(4) VF_DP_CASE(5) VF_DP_CASE(6) VF_DP_CASE(7) VF_DP_CASE(8)
@@ -1622,7 +1682,12 @@ hipError_t launch_filter(hipStream_t s, int W, const uint32_t *rows, const uint1
                          BatchLists bl, uint64_t *counters) {
     if (bl.grid == 0) return hipSuccess;
     const int g = (int)bl.grid;                       // one workgroup per list segment (<= kMaxGrid)
-    hipLaunchKernelGGL(k_filter, dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, counters);
+    switch (W) {
+    case 10: hipLaunchKernelGGL(k_filter<10>, dim3(g), dim3(kBlock), 0, s, rows, lens, dp, spans, bl, counters); break;
+    case 20: hipLaunchKernelGGL(k_filter<20>, dim3(g), dim3(kBlock), 0, s, rows, lens, dp, spans, bl, counters); break;
+    case 40: hipLaunchKernelGGL(k_filter<40>, dim3(g), dim3(kBlock), 0, s, rows, lens, dp, spans, bl, counters); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
@@ -1633,6 +1698,7 @@ hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint1
     hipError_t e = ensure_lut();
     if (e != hipSuccess) return e;
     static const int per_cu = [] { const char *v = getenv("VFIND_FINISH_BLOCKS_PER_CU"); const int x = v ? atoi(v) : 8; return x >= 1 && x <= 8 ? x : 8; }();
+    static const bool u2 = [] { const char *v = getenv("VFIND_FINISH_U"); return !v || atoi(v) != 1; }();
     const int g = grid_for(n, per_cu);
 #define VF_FINISH(WW, UU)                                                                                              \
     do {                                                                                                               \
@@ -1640,7 +1706,15 @@ hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint1
         else hipLaunchKernelGGL((k_finish<WW, UU, false>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t);               \
     } while (0)
     switch (W) {
-    case 10: VF_FINISH(10, 2); break;
+    case 10: {
+        static const int dbg = [] { const char *v = getenv("VFIND_FINISH_DBG"); return v ? atoi(v) : 0; }();
+        if (dbg == 1) hipLaunchKernelGGL((k_finish<10, 2, false, 1>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t);
+        else if (dbg == 2) hipLaunchKernelGGL((k_finish<10, 2, false, 2>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t);
+        else if (dbg == 3) hipLaunchKernelGGL((k_finish<10, 2, false, 3>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t);
+        else if (dbg == 4) hipLaunchKernelGGL((k_finish<10, 2, false, 4>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t);
+        else if (u2) VF_FINISH(10, 2); else VF_FINISH(10, 1);
+        break;
+    }
     case 20: VF_FINISH(20, 1); break;
     case 40: VF_FINISH(40, 1); break;
     default: return hipErrorInvalidValue;
