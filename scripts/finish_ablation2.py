@@ -1,20 +1,15 @@
-import sys, os
-sys.path.insert(0, '.')
-import numpy as np, torch
-import vfind_amd
-from vfind_amd import synth
-n = 10_000_000
-ads = synth.adapters(0x5EED0002, 20)
-gen = synth.Generator(0x5EED0002, ads)
-rows_h, lens_h = gen.packed(0, n, 16)
-rows = torch.from_numpy(rows_h).cuda(); lens = torch.from_numpy(lens_h.view(np.int16)).cuda()
-for flags in ("0", "0x200", "0x100"):
-    os.environ["VFIND_DEBUG_FLAGS"] = flags
-    eng = vfind_amd.Engine(ads, table_slots=1 << 22)
-    eng.process_device(rows.data_ptr(), gen.row_dwords, lens.data_ptr(), n); eng.sync()
-    eng.reset_stats(); eng.set_profiling(True)
-    for _ in range(3):
-        eng.process_device(rows.data_ptr(), gen.row_dwords, lens.data_ptr(), n)
-    eng.sync(); st = eng.stats()
-    print(f"flags={flags} warm: finish {st['ms_finish']/3:.3f} ms", flush=True)
-    eng.close()
+"""k_finish ablation through the kernel's compile-time switches (VFIND_FINISH_DBG, read once per process):
+0 = product path, 1 = no slot-line loads, 2 = no row loads, 3 = no slot-line loads and no counting,
+4 = slot-line loads but no counting.  Modes 1-4 give wrong counts by construction (profiling only).
+Each mode runs bench.py in its own process, cold (table cleared every step) and warm (table kept).
+Round 1 on one MI355X, cfg 2: warm 0.547 / 0.518 / 0.646 / 0.063 / 0.271 ms -> counting, not probing,
+was the cost; that is what moved the counts to per-XCD arrays with L2-local atomics."""
+import json, os, subprocess, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for keep in ("0", "1"):
+    for dbg in ("0", "1", "2", "3", "4"):
+        env = dict(os.environ, VFIND_FINISH_DBG=dbg, VFIND_BENCH_KEEP_TABLE=keep, VFIND_RES_LANES="1")
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-parity"], env=env,
+                             capture_output=True, text=True, timeout=600).stdout.strip().splitlines()[-1]
+        d = json.loads(out)
+        print(f"table {'kept' if keep == '1' else 'cleared'} dbg={dbg}: finish {d['roofline_path']['kernel_ms_per_step']['finish']:.3f} ms, step {d['ms_per_step']:.3f} ms", flush=True)
