@@ -239,7 +239,7 @@ def main():
             "cpu_baseline": cpu,
             "parity_gate": parity, "parity_full_size": parity_full, "table_cleared_each_step": not keep_table,
             "merge_ms": None if merge_ms is None else round(merge_ms, 3),
-            "per_step": {"dp_prefix_tasks": st["dp_prefix"] // steps, "dp_suffix_tasks": st["dp_suffix"] // steps,
+            "per_step": {"dp_prefix_tasks": st["dp_prefix"] // steps, "dp_suffix_tasks": st["dp_suffix"] // steps, "insert_path_reads": st["insert_path"] // steps,
                          "accepted": st["accepted"] // steps, "counted": st["counted"] // steps,
                          "table_entries": st["table_entries"]},
             "gen_s": round(t_gen, 2),

@@ -78,6 +78,7 @@ typedef struct vf_stats {
        adapters), dp_rest = the side stream's group of small window classes + full-width DP */
     double ms_scan, ms_filter, ms_dp_window, ms_dp_rest, ms_finish, ms_generic;
     uint64_t launches_scan, launches_filter, launches_dp_window, launches_dp_rest, launches_finish, launches_generic;
+    uint64_t insert_path;      /* counted reads whose one-shot table lookup missed (new, displaced or racing keys) */
 } vf_stats;
 
 const char *vf_last_error(void);

@@ -33,7 +33,8 @@ class VfStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "reads", "reads_generic", "dp_prefix", "dp_suffix", "accepted", "counted", "table_entries", "arena_dwords")] + [
         (n, C.c_double) for n in ("ms_scan", "ms_filter", "ms_dp_window", "ms_dp_rest", "ms_finish", "ms_generic")] + [
-        (n, C.c_uint64) for n in ("launches_scan", "launches_filter", "launches_dp_window", "launches_dp_rest", "launches_finish", "launches_generic")]
+        (n, C.c_uint64) for n in ("launches_scan", "launches_filter", "launches_dp_window", "launches_dp_rest", "launches_finish", "launches_generic",
+                                  "insert_path")]
 
 
 # every symbol include/vfind_hip.h declares: (name, restype, argtypes)

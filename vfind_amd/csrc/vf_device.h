@@ -76,7 +76,8 @@ enum Counter : int {        // uint64 counters[] in device memory
     C_DP_SUFFIX = 7,
     C_EXPORT_N = 8,
     C_EXPORT_KEYS = 9,
-    C_NUM = 10
+    C_SLOW = 10,            // reads k_finish sent through the insert path (one-shot lookup missed)
+    C_NUM = 11
 };
 constexpr int kTableCounters = 4;       // C_ARENA_TOP..C_KEY_DWORDS are reset with the table
 

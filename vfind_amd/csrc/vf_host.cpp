@@ -1105,7 +1105,7 @@ extern "C" int vf_stats_get(vf_ctx *c, vf_stats *o) {
     memset(o, 0, sizeof(*o));
     o->reads = c->n_reads; o->reads_generic = c->n_generic;
     o->dp_prefix = h[C_DP_PREFIX]; o->dp_suffix = h[C_DP_SUFFIX];
-    o->accepted = h[C_ACCEPTED]; o->counted = h[C_COUNTED];
+    o->accepted = h[C_ACCEPTED]; o->counted = h[C_COUNTED]; o->insert_path = h[C_SLOW];
     o->table_entries = h[C_ENTRIES]; o->arena_dwords = h[C_KEY_DWORDS];
     o->ms_scan = c->ms[K_SCAN]; o->ms_filter = c->ms[K_FILTER]; o->ms_dp_window = c->ms[K_DPW]; o->ms_dp_rest = c->ms[K_DPREST];
     o->ms_finish = c->ms[K_FIN]; o->ms_generic = c->ms[K_GEN];
@@ -1122,6 +1122,7 @@ extern "C" int vf_stats_reset(vf_ctx *c) {
     for (int k = 0; k < K_KINDS; ++k) { c->ms[k] = 0; c->launches[k] = 0; }
     const uint64_t z[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(c->t_counters.p + C_ACCEPTED, z, 4 * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->t_counters.p + C_SLOW, z, sizeof(uint64_t), hipMemcpyHostToDevice));
     return VF_OK;
 }
 extern "C" int vf_set_profiling(vf_ctx *c, int on) {

@@ -1198,10 +1198,10 @@ __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ 
     __shared__ uint8_t lut[64];
     __shared__ Agg agg;
     __shared__ BlockTable bt;
-    __shared__ uint32_t s_stat[2];
+    __shared__ uint32_t s_stat[3];
     __shared__ uint32_t s_slow[kBlock / WAVE][kSlowCap];
     if (threadIdx.x < 64) lut[threadIdx.x] = c_codon_le[threadIdx.x];
-    if (threadIdx.x < 2) s_stat[threadIdx.x] = 0;
+    if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
     agg_init(agg);
     block_table_begin(bt, t);
     __syncthreads();
@@ -1289,6 +1289,7 @@ __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ 
                     const uint64_t m = __ballot(miss);
                     if (miss) slow[nslow + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r[u];
                     nslow += (uint32_t)__popcll(m);
+                    if (m && lane == 0) atomicAdd(&s_stat[2], (uint32_t)__popcll(m));
                     // capacity: < 64 queued before a trip, at most 64 more per read of the trip
                 }
             }
@@ -1322,6 +1323,7 @@ __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ 
     if (threadIdx.x == 0) {
         if (s_stat[0]) atomicAdd((unsigned long long *)&t.counters[C_ACCEPTED], (unsigned long long)s_stat[0]);
         if (s_stat[1]) atomicAdd((unsigned long long *)&t.counters[C_COUNTED], (unsigned long long)s_stat[1]);
+        if (s_stat[2]) atomicAdd((unsigned long long *)&t.counters[C_SLOW], (unsigned long long)s_stat[2]);
     }
 }
 
