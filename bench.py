@@ -215,9 +215,9 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")))["kernels"]
-            kname = {"scan": "vf::k_scan<10>", "finish": "vf::k_finish<10>"}.get(dom)
-            if kname and L == 150 and n == 10_000_000:
-                traffic = pmc.get(kname, {}).get("traffic")
+            prefix = {"scan": "vf::k_scan<10", "finish": "vf::k_finish<10"}.get(dom)
+            if prefix and L == 150 and n == 10_000_000:
+                traffic = next((v.get("traffic") for k, v in pmc.items() if k.startswith(prefix)), None)
         except Exception:
             traffic = None
         # whole path: wall time per step (two batch lanes overlap, so per-kernel times sum to more than this)
