@@ -83,6 +83,55 @@ def test_spans_parity_random(seed, L, sub, indel):
     assert (st >= 0).sum() > 100 and (en >= 0).sum() > 100
 
 
+@pytest.mark.parametrize("m", [8, 9, 12, 16, 17, 20, 24, 32])
+def test_exact_scan_decoys(m):
+    """the exact search checks (up to) eight pattern bases at every position and the whole pattern only at
+    the survivors: decoys that agree with the adapter on exactly those bases - before, after, overlapping
+    and at the very end of the read - must not move memmem's leftmost answer"""
+    rng = np.random.default_rng(1000 + m)
+    B = b"ACGT"
+    def rand(k):
+        return bytes(B[i] for i in rng.integers(0, 4, k))
+    pre, suf = rand(m), rand(m)
+    while suf == pre:
+        suf = rand(m)
+    # bases stage 1 looks at (vf_kernels.hip scan_plan): pairs (b, b+16) while the adapter is longer than 16 + b, then singles
+    pairs = max(0, min(4, m - 16))
+    singles = max(0, min(8 - 2 * pairs, min(m, 16) - pairs))
+    checked = set(range(pairs + singles)) | {b + 16 for b in range(pairs)}
+    def decoy(ad):
+        d = bytearray(ad)
+        free = [i for i in range(m) if i not in checked]
+        if not free:                                   # m <= 8: stage 1 is already exact
+            d[rng.integers(0, m)] = B[(B.index(bytes([d[0]])) + 1) % 4]
+            return bytes(d)
+        for i in rng.choice(free, size=max(1, len(free) // 2), replace=False):
+            d[i] = B[(B.index(bytes([d[i]])) + 1 + rng.integers(0, 3)) % 4]
+        return bytes(d)
+    reads = []
+    for k in range(400):
+        parts = [rand(int(rng.integers(0, 12)))]
+        for ad in (pre, suf):
+            shape = k % 8
+            if shape in (0, 1): parts += [decoy(ad), rand(int(rng.integers(0, 9))), ad]              # decoy first
+            elif shape == 2: parts += [ad, rand(3), decoy(ad)]                                    # decoy after
+            elif shape == 3: parts += [decoy(ad)[: m // 2], ad]                                   # half a decoy runs into the real one
+            elif shape == 4: parts += [decoy(ad), decoy(ad), ad, ad]                              # two decoys, two copies
+            elif shape == 5: parts += [decoy(ad)]                                                 # decoy only
+            elif shape == 6: parts += [ad[:-1]]                                                   # truncated copy
+            else: parts += [rand(5), ad]
+            parts.append(rand(int(rng.integers(6, 30))))
+        if k % 16 == 7:
+            parts.append(pre)                                                                     # a copy flush with the read end
+        if k % 16 == 15:
+            parts.append(decoy(suf))                                                              # a decoy flush with the read end
+        reads.append(b"".join(parts)[:600])
+    # exact-only mode isolates the scan; the default mode adds the alignment of the decoys
+    _check_spans(reads, (pre.decode(), suf.decode()), accept_prefix_alignment=1.0, accept_suffix_alignment=1.0)
+    _check_spans(reads, (pre.decode(), suf.decode()))
+    _check_counts(reads, (pre.decode(), suf.decode()), skip_translation=True)
+
+
 def test_spans_parity_tie_sensitive_reads_follow_policy_P():
     # reads whose optimal alignment is not unique: the kernel must agree with the oracle's tie
     # policy P, and the length it reports must be one of the co-optimal lengths
@@ -373,6 +422,28 @@ def test_capacity_error_is_loud():
         assert e.stats()["arena_dwords"] > (1 << 10)
     assert got == oracle.count(long_reads, AD20, skip_translation=True)
     assert max(len(k) for k in got) > 224
+
+
+@pytest.mark.parametrize("n_variants,zipf", [(300, 1.1), (200000, 0.0)])
+def test_counts_large_batch_hot_and_flat_keys(n_variants, zipf):
+    """a million reads through the resident path: a few hundred hot keys (LDS aggregation, per-XCD count
+    arrays summed at export) and a flat library (nearly every read a new or rare key: insert path)"""
+    import torch
+    from vfind_amd import Engine, synth as vsynth
+    gen = vsynth.Generator(0xC0FFEE + n_variants, AD20, n_variants=n_variants, zipf_s=zipf)
+    n = 1_000_000
+    rows, lens = gen.packed(0, n, 8)
+    data, offs = gen.ascii(0, n, 8)
+    want = oracle.count((data, offs), AD20, n_threads=8)
+    d_rows = torch.from_numpy(rows).cuda()
+    d_lens = torch.from_numpy(lens.view("int16")).cuda()
+    with Engine(AD20, table_slots=1 << 20) as e:
+        for _ in range(2):                             # cold, then onto existing keys
+            e.process_device(d_rows.data_ptr(), rows.shape[1], d_lens.data_ptr(), n)
+        got = e.finish_dict()
+        st = e.stats()
+    assert got == {k: 2 * v for k, v in want.items()}
+    assert st["counted"] == 2 * sum(want.values()) and st["insert_path"] >= len(want)
 
 
 def test_arrow_export_frame():
