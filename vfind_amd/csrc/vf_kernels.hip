@@ -566,7 +566,10 @@ __device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int
         for (int wi = 0; wi < CW; ++wi) {
             const int w = c * CW + wi;
             if (w < nw_max) {                          // wave-uniform
-                const uint32_t word = x[wi];
+                uint32_t word = x[wi];
+                // ties this word's LDS addresses to the state the previous word leaves: without it the compiler
+                // computes all 80 addresses of a chunk up front (149 VGPRs, 3 waves per SIMD)
+                asm volatile("" : "+v"(word), "+v"(Pv));
                 uint32_t det = 0;                      // one bit per column, newest in bit 0
                 uint2 e[8];
 #pragma unroll
