@@ -19,7 +19,8 @@ def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("h") / "fastq_harness")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "fastq_harness.cpp"),
-                           os.path.join(ROOT, "vfind_amd", "csrc", "vf_fastq.cpp"), "-o", exe, "-lz", "-lpthread"])
+                           os.path.join(ROOT, "vfind_amd", "csrc", "vf_fastq.cpp"),
+                           os.path.join(ROOT, "vfind_amd", "csrc", "vf_inflate.cpp"), "-o", exe, "-lz", "-lpthread"])
     return exe
 
 

@@ -4,7 +4,7 @@
 //   [inflate pool] --text pieces--> [sequencer] --whole-record chunks--> [frame+pack pool] --> GPU
 //
 // * The compressed file is mmapped.  gzip members are independent deflate streams, so members are
-//   inflated in parallel (zlib).  A decode task starts at a member start and runs through whole
+//   inflated in parallel (vf_inflate.cpp; VFIND_INFLATE=zlib selects zlib instead).  A decode task starts at a member start and runs through whole
 //   members until the first member end at or beyond the next 4 MiB grid line that is itself a member
 //   start (or EOF).  Task starts are claimed speculatively ("first gzip magic at or after the grid
 //   line"): exact for BGZF and for ordinary multi-member files; a claim that was wrong (magic bytes
@@ -14,10 +14,11 @@
 // * The sequencer consumes tasks in file order (a task is consumed only if it starts exactly where the
 //   previous one ended), counts newlines to cut the text into chunks of whole four-line records and
 //   hands them to the frame+pack workers, which call the batch submission path.
-// * Every member's CRC32/ISIZE trailer is verified by zlib; trailing garbage, truncation and malformed
+// * Every member's CRC32/ISIZE trailer is verified; trailing garbage, truncation and malformed
 //   records surface as VF_EFORMAT (the reference panics there, lib.rs:308).
 #include "../../include/vfind_hip.h"
 #include "vf_internal.h"
+#include "vf_inflate.h"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -144,7 +145,69 @@ struct Reader {
 static uint64_t next_grid(uint64_t s) { return (s / kGrid + 1) * kGrid; }
 
 // inflate whole members from t->start until the task's end rule fires
+static void run_task_zlib(Reader &R, const std::shared_ptr<Task> &t);
 static void run_task(Reader &R, const std::shared_ptr<Task> &t) {
+    static const bool use_zlib = [] { const char *e = getenv("VFIND_INFLATE"); return e && !strcmp(e, "zlib"); }();
+    if (use_zlib) { run_task_zlib(R, t); return; }
+    std::unique_ptr<vf::GzipMemberDecoder> dec(new vf::GzipMemberDecoder);
+    const uint8_t *file_end = R.file + R.size;
+    const uint64_t stop_at = next_grid(t->start);
+    dec->begin(R.file + t->start, file_end);
+    Piece piece;
+    piece.data = R.pieces.get();
+    size_t fill = 0;
+    auto flush_piece = [&](bool final_piece) -> bool {      // returns false when aborted
+        std::unique_lock<std::mutex> lk(R.mu);
+        if (fill) {
+            piece.size = fill;
+            t->buffered += fill;
+            R.total_buffered += fill;
+            t->out.push_back(piece);
+            piece = Piece();
+            fill = 0;
+            R.cv.notify_all();
+        }
+        if (!final_piece && !piece.data) { lk.unlock(); piece.data = R.pieces.get(); lk.lock(); }
+        if (final_piece) return true;
+        // a task nobody needs yet may only run so far ahead; and it gives way when the sequencer is
+        // blocked on a task no worker is decoding (a false start can inflate garbage for a long time,
+        // and with few workers it would otherwise hold the last one)
+        auto starving = [&] { return R.required != kNone && R.required != t->start && !R.tasks.count(R.required); };
+        R.cv.wait(lk, [&] { return t->abort || R.stop || t->start == R.head_pos || starving() || t->buffered <= spec_cap(); });
+        if (t->start != R.head_pos && starving()) t->abort = true;
+        return !(t->abort || R.stop);
+    };
+    bool ok = true;
+    std::string err;
+    uint64_t end = 0;
+    for (;;) {
+        if (kPiece - fill < 4096 && !flush_piece(false)) { ok = false; err = "aborted"; break; }
+        size_t got = 0;
+        const vf::GzipMemberDecoder::Status st = dec->run(piece.data + fill, kPiece - fill, &got);
+        fill += got;
+        t->in_pos.store((uint64_t)(dec->in_pos() - R.file), std::memory_order_relaxed);
+        if (st == vf::GzipMemberDecoder::kError) { ok = false; err = dec->error(); break; }
+        if (st == vf::GzipMemberDecoder::kPieceFull) {
+            if (!flush_piece(false)) { ok = false; err = "aborted"; break; }
+            continue;
+        }
+        const uint64_t e = (uint64_t)(dec->in_pos() - R.file);      // absolute offset just past this member
+        if (e >= R.size) { end = R.size; break; }
+        if (e >= stop_at && R.is_member_start(e)) { end = e; break; }
+        dec->begin(R.file + e, file_end);       // next member of the same task (or trailing garbage, which the header check rejects)
+    }
+    if (ok) (void)flush_piece(true);
+    R.pieces.put(piece.data);
+    std::lock_guard<std::mutex> g(R.mu);
+    t->failed = !ok;
+    t->err = err;
+    t->end = end;
+    t->done = true;
+    R.cv.notify_all();
+}
+
+// the same task on zlib (VFIND_INFLATE=zlib): kept for A/B runs
+static void run_task_zlib(Reader &R, const std::shared_ptr<Task> &t) {
     z_stream z;
     memset(&z, 0, sizeof(z));
     if (inflateInit2(&z, 31) != Z_OK) {
