@@ -25,6 +25,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -70,7 +73,25 @@ struct BufPool {
     void put(uint8_t *p) { if (p) { std::lock_guard<std::mutex> g(mu); free_list.push_back(p); } }
 };
 
-struct Piece { uint8_t *data = nullptr; size_t size = 0; };
+struct Piece { uint8_t *data = nullptr; size_t size = 0; size_t nl = 0; };      // nl = newlines, counted by the inflate worker
+
+// newline count of a piece (SSE2: 16 bytes a step; the inflate workers run it in parallel while the
+// text is still in their caches, so the one sequencer thread never scans text itself)
+static size_t count_newlines(const uint8_t *p, size_t n) {
+    size_t c = 0, i = 0;
+#if defined(__SSE2__)
+    const __m128i nlv = _mm_set1_epi8('\n');
+    for (; i + 64 <= n; i += 64) {
+        const unsigned m0 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i)), nlv));
+        const unsigned m1 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i + 16)), nlv));
+        const unsigned m2 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i + 32)), nlv));
+        const unsigned m3 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i + 48)), nlv));
+        c += (size_t)__builtin_popcountll((uint64_t)m0 | ((uint64_t)m1 << 16) | ((uint64_t)m2 << 32) | ((uint64_t)m3 << 48));
+    }
+#endif
+    for (; i < n; ++i) c += p[i] == '\n';
+    return c;
+}
 
 struct Task {
     uint64_t start = 0, end = 0;
@@ -81,7 +102,15 @@ struct Task {
     std::string err;
 };
 
-struct Chunk { uint8_t *text = nullptr; size_t size = 0; };
+// A chunk of whole records is a list of byte ranges inside inflate pieces; a piece goes back to its pool
+// when the last chunk that references it has been copied out by a frame+pack worker.
+struct PieceHold {
+    uint8_t *data; BufPool *pool;
+    PieceHold(uint8_t *d, BufPool *p) : data(d), pool(p) {}
+    ~PieceHold() { pool->put(data); }
+};
+struct Seg { std::shared_ptr<PieceHold> hold; const uint8_t *p = nullptr; size_t n = 0; };
+struct Chunk { std::vector<Seg> segs; size_t size = 0; };
 
 template <typename T> struct BoundedQueue {
     std::mutex mu;
@@ -157,9 +186,11 @@ static void run_task(Reader &R, const std::shared_ptr<Task> &t) {
     piece.data = R.pieces.get();
     size_t fill = 0;
     auto flush_piece = [&](bool final_piece) -> bool {      // returns false when aborted
+        const size_t nl_count = fill ? count_newlines(piece.data, fill) : 0;
         std::unique_lock<std::mutex> lk(R.mu);
         if (fill) {
             piece.size = fill;
+            piece.nl = nl_count;
             t->buffered += fill;
             R.total_buffered += fill;
             t->out.push_back(piece);
@@ -221,9 +252,11 @@ static void run_task_zlib(Reader &R, const std::shared_ptr<Task> &t) {
     piece.data = R.pieces.get();
     size_t fill = 0;
     auto flush_piece = [&](bool final_piece) -> bool {      // returns false when aborted
+        const size_t nl_count = fill ? count_newlines(piece.data, fill) : 0;
         std::unique_lock<std::mutex> lk(R.mu);
         if (fill) {
             piece.size = fill;
+            piece.nl = nl_count;
             t->buffered += fill;
             R.total_buffered += fill;
             t->out.push_back(piece);
@@ -418,7 +451,11 @@ extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
 
     // ---- frame + pack workers -----------------------------------------------------------------
     std::vector<std::thread> packers;
-    const uint32_t npack = std::max<uint32_t>(1, (nthreads + 1) / 2);   // framing + packing is lighter than inflate
+    // n_threads inflate workers (the reference's n_threads are its alignment workers, next to one reader) and
+    // half as many frame + pack workers, whose per-read work is lighter; the environment can override the split
+    auto env_u = [](const char *k, uint32_t dflt) { const char *e = getenv(k); const int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : dflt; };
+    const uint32_t ninfl = env_u("VFIND_FASTQ_INFLATERS", nthreads);
+    const uint32_t npack = env_u("VFIND_FASTQ_PACKERS", std::max<uint32_t>(1, (nthreads + 1) / 2));
     for (uint32_t w = 0; w < npack; ++w) {
         packers.emplace_back([&] {
             std::vector<ReadRef> refs;
@@ -427,15 +464,19 @@ extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
                 if (failed.load()) continue;
                 refs.clear();
                 std::string err;
-                int rc = frame_records(ch->text, ch->size, refs, err);
+                // the chunk's byte ranges -> one contiguous buffer (this copy used to sit on the sequencer thread)
+                uint8_t *text = chunk_pool.get();
+                size_t at = 0;
+                for (auto &sg : ch->segs) { memcpy(text + at, sg.p, sg.n); at += sg.n; }
+                ch->segs.clear();                            // pieces return to their pool
+                int rc = frame_records(text, at, refs, err);
                 if (!rc) {
                     if (g_dbg) fprintf(stderr, "[fastq] packer submits %zu reads at %.3f\n", refs.size(), now_s());
-                    rc = vf_internal_submit(c, ch->text, refs.data(), refs.size());
+                    rc = vf_internal_submit(c, text, refs.data(), refs.size());
                     if (g_dbg) fprintf(stderr, "[fastq] packer submitted rc=%d at %.3f\n", rc, now_s());
                     if (rc) err = vf_internal_last_error();
                 }
-                chunk_pool.put(ch->text);
-                ch->text = nullptr;
+                chunk_pool.put(text);
                 if (rc) { fail_async(rc, err); break; }
             }
         });
@@ -447,7 +488,7 @@ extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
         R.required = 0;
     }
     std::vector<std::thread> inflaters;
-    for (uint32_t w = 0; w < nthreads; ++w) inflaters.emplace_back([&] { inflate_worker(R); });
+    for (uint32_t w = 0; w < ninfl; ++w) inflaters.emplace_back([&] { inflate_worker(R); });
 
     std::atomic<bool> watch_stop{false};
     std::thread watchdog;
@@ -465,32 +506,46 @@ extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
     });
 
     // ---- sequencer (this thread) ----------------------------------------------------------------
+    // Bookkeeping only: pieces arrive with their newline counts, so the running line count mod 4 tells how
+    // many newlines back from the end of the collected text the last record boundary lies.
     std::unique_ptr<Chunk> cur(new Chunk);
-    cur->text = chunk_pool.get();
-    size_t scan_pos = 0, lines = 0, cut = 0;
+    size_t lines = 0;
     auto emit_full = [&](bool final_flush) -> bool {
-        // count newlines in the unscanned tail; cut after the last complete record
-        const uint8_t *t = cur->text;
-        const size_t n = cur->size;
-        while (scan_pos < n) {
-            const void *q = memchr(t + scan_pos, '\n', n - scan_pos);
-            if (!q) { scan_pos = n; break; }
-            scan_pos = (size_t)((const uint8_t *)q - t) + 1;
-            if (++lines % 4 == 0) cut = scan_pos;
-        }
-        if (final_flush) cut = n;                        // the last record may lack its newline
-        if (cut == 0) return true;
+        if (cur->size == 0) return true;
         std::unique_ptr<Chunk> next(new Chunk);
-        next->text = chunk_pool.get();
-        next->size = n - cut;
-        memcpy(next->text, t + cut, n - cut);
-        cur->size = cut;
+        size_t carried_lines = 0;
+        if (!final_flush) {                              // (at the very end the last record may lack its newline)
+            // cut just after the (k+1)-th newline from the end, k = complete lines past the last whole record
+            int need = (int)(lines % 4) + 1;
+            int si = (int)cur->segs.size() - 1;
+            size_t off = 0;
+            bool found = false;
+            for (; si >= 0 && !found; --si) {
+                const Seg &sg = cur->segs[(size_t)si];
+                size_t len = sg.n;
+                while (len) {
+                    const void *q = memrchr(sg.p, '\n', len);
+                    if (!q) break;
+                    len = (size_t)((const uint8_t *)q - sg.p);
+                    if (--need == 0) { off = len + 1; found = true; break; }
+                }
+                if (found) break;
+            }
+            if (!found) return true;                     // less than one whole record so far
+            carried_lines = lines % 4;
+            // everything after (si, off) moves to the next chunk
+            Seg &cut = cur->segs[(size_t)si];
+            if (off < cut.n) { Seg tail = cut; tail.p += off; tail.n -= off; next->segs.push_back(tail); next->size += tail.n; }
+            for (size_t j = (size_t)si + 1; j < cur->segs.size(); ++j) { next->size += cur->segs[j].n; next->segs.push_back(std::move(cur->segs[j])); }
+            cur->segs.resize((size_t)si + 1);
+            cur->segs[(size_t)si].n = off;
+            cur->size -= next->size;
+            if (cur->size == 0) { cur = std::move(next); lines = carried_lines; return true; }
+        }
         if (g_dbg) fprintf(stderr, "[fastq] sequencer emits chunk of %zu bytes at %.3f\n", cur->size, now_s());
-        if (!chunks.put(std::move(cur))) { chunk_pool.put(next->text); return false; }
+        if (!chunks.put(std::move(cur))) return false;
         cur = std::move(next);
-        scan_pos = 0;                                    // the carried tail (less than one record) is rescanned
-        lines = 0;
-        cut = 0;
+        lines = carried_lines;
         return true;
     };
 
@@ -542,9 +597,12 @@ extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
                     ok = false;
                     break;
                 }
-                memcpy(cur->text + cur->size, p.data, p.size);
+                Seg sg;
+                sg.hold = std::make_shared<PieceHold>(p.data, &R.pieces);
+                sg.p = p.data; sg.n = p.size;
+                cur->segs.push_back(std::move(sg));
                 cur->size += p.size;
-                R.pieces.put(p.data);
+                lines += p.nl;
                 if (cur->size >= kChunkTarget && !emit_full(false)) { ok = false; break; }
                 continue;
             }
@@ -573,7 +631,7 @@ extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
         R.cv.notify_all();
     }
     if (ok && !failed.load() && cur->size) ok = emit_full(true);
-    if (cur && cur->text) chunk_pool.put(cur->text);
+    cur.reset();
 
     {
         std::lock_guard<std::mutex> g(R.mu);
