@@ -170,25 +170,46 @@ def main():
             raise SystemExit("PARITY FAILED at full size: device table differs from the CPU oracle")
     oracle_full = None
 
-    # ---- final (key,count) merge across GPUs over RCCL (xGMI), timed separately ------------------
-    merge_ms = None
+    # the metric first: max over ranks of the timed region
     counted_local = st["counted"] // max(args.steps, 1)
     if world > 1:
-        tot = torch.tensor([counted_local], dtype=torch.int64, device=wire)
-        dist.all_reduce(tot)
-        barrier()
-        tm = time.perf_counter()
-        eng.allreduce_table(dst=0)
-        torch.cuda.synchronize(dev)
-        barrier()
-        merge_ms = (time.perf_counter() - tm) * 1e3
-        if rank == 0:
-            keys, offs, cnts = eng.finish_arrays()
-            if int(cnts.sum()) != int(tot.item()):
-                raise SystemExit("MERGE CHECK FAILED: merged counts do not sum to the per-rank totals")
         t_el = torch.tensor([elapsed], dtype=torch.float64, device=wire)
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
         elapsed = float(t_el.item())
+
+    # ---- final (key,count) merge across GPUs over RCCL (xGMI), timed separately ------------------
+    # Runs under a watchdog: the bench line must come out even if the exchange stalls on some fabric.
+    merge_ms, merge_error = None, None
+    if world > 1:
+        import threading
+        box = {}
+
+        def do_merge():
+            try:
+                tot = torch.tensor([counted_local], dtype=torch.int64, device=wire)
+                dist.all_reduce(tot)
+                barrier()
+                tm = time.perf_counter()
+                eng.allreduce_table(dst=0)
+                torch.cuda.synchronize(dev)
+                barrier()
+                box["ms"] = (time.perf_counter() - tm) * 1e3
+                if rank == 0:
+                    keys, offs, cnts = eng.finish_arrays()
+                    if int(cnts.sum()) != int(tot.item()):
+                        box["err"] = "merged counts do not sum to the per-rank totals"
+            except Exception as e:                        # noqa: BLE001 - reported in the JSON line
+                box["err"] = f"{type(e).__name__}: {e}"
+
+        th = threading.Thread(target=do_merge, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("VFIND_BENCH_MERGE_TIMEOUT", "120")))
+        if th.is_alive():
+            merge_error = "table merge did not finish in time"
+        else:
+            merge_ms, merge_error = box.get("ms"), box.get("err")
+        if merge_error and "do not sum" in merge_error:
+            raise SystemExit("MERGE CHECK FAILED: " + merge_error)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -238,13 +259,16 @@ def main():
                               "kernel_ms_per_step": {k: round(v[0] / steps, 4) for k, v in kern.items()}},
             "cpu_baseline": cpu,
             "parity_gate": parity, "parity_full_size": parity_full, "table_cleared_each_step": not keep_table,
-            "merge_ms": None if merge_ms is None else round(merge_ms, 3),
+            "merge_ms": None if merge_ms is None else round(merge_ms, 3), "merge_error": merge_error,
             "per_step": {"dp_prefix_tasks": st["dp_prefix"] // steps, "dp_suffix_tasks": st["dp_suffix"] // steps, "insert_path_reads": st["insert_path"] // steps,
                          "accepted": st["accepted"] // steps, "counted": st["counted"] // steps,
                          "table_entries": st["table_entries"]},
             "gen_s": round(t_gen, 2),
         }
         print(json.dumps(out), flush=True)
+    if merge_error == "table merge did not finish in time":
+        sys.stdout.flush()
+        os._exit(0)                                       # the stuck collective would block close() as well
     eng.close()
     if world > 1:
         dist.destroy_process_group()
