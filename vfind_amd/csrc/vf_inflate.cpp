@@ -1,4 +1,4 @@
-// vf_inflate.cpp -- streaming gzip member decoder (see vf_inflate.h)
+// vf_inflate.cpp -- deflate / gzip decoding (see vf_inflate.h)
 #include "vf_inflate.h"
 
 #include <cstring>
@@ -26,19 +26,37 @@ inline uint64_t load64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return 
 
 }  // namespace
 
-void GzipMemberDecoder::begin(const uint8_t *in, const uint8_t *in_end) {
-    in_ = in; in_end_ = in_end;
+template <typename T>
+void DeflateCore<T>::begin(const uint8_t *base, const uint8_t *in_end, uint64_t bit_pos) {
+    base_ = base; in_end_ = in_end;
+    in_ = base + (bit_pos >> 3);
+    if (in_ > in_end_) in_ = in_end_;
     bitbuf_ = 0; bitcnt_ = 0;
-    state_ = kGzipHeader;
+    const int skip = (int)(bit_pos & 7u);
+    if (skip && in_ < in_end_) { bitbuf_ = (uint64_t)*in_++ >> skip; bitcnt_ = 8 - skip; }
+    stop_bit_ = ~0ull;
+    state_ = kBlockHeader;
     last_block_ = false;
     stored_left_ = 0;
-    crc_ = 0;
-    total_out_ = 0;
     hist_len_ = 0;
     err_ = "";
 }
 
-bool GzipMemberDecoder::need_bits(int n) {
+template <typename T>
+void DeflateCore<T>::set_history(const T *text, size_t n) {
+    if (n > kDeflateWindow) { text += n - kDeflateWindow; n = kDeflateWindow; }
+    memmove(hist_, text, n * sizeof(T));
+    hist_len_ = n;
+}
+
+template <typename T>
+void DeflateCore<T>::fill_markers() {
+    for (size_t i = 0; i < kDeflateWindow; ++i) hist_[i] = (T)(kMarkerBase + i);
+    hist_len_ = kDeflateWindow;
+}
+
+template <typename T>
+bool DeflateCore<T>::need_bits(int n) {
     while (bitcnt_ < n) {
         if (in_ >= in_end_) return false;
         bitbuf_ |= (uint64_t)*in_++ << bitcnt_;
@@ -47,40 +65,9 @@ bool GzipMemberDecoder::need_bits(int n) {
     return true;
 }
 
-// RFC 1952 member header
-bool GzipMemberDecoder::parse_gzip_header() {
-    const uint8_t *p = in_;
-    if (in_end_ - p < 10) { err_ = "gzip error: truncated stream"; return false; }
-    if (p[0] != 0x1f || p[1] != 0x8b) { err_ = "gzip error: invalid gzip header"; return false; }
-    if (p[2] != 8) { err_ = "gzip error: unknown compression method"; return false; }
-    const uint8_t flg = p[3];
-    if (flg & 0xE0) { err_ = "gzip error: unknown header flags set"; return false; }
-    p += 10;
-    if (flg & 4) {                                         // FEXTRA
-        if (in_end_ - p < 2) { err_ = "gzip error: truncated stream"; return false; }
-        const size_t xlen = (size_t)p[0] | ((size_t)p[1] << 8);
-        p += 2;
-        if ((size_t)(in_end_ - p) < xlen) { err_ = "gzip error: truncated stream"; return false; }
-        p += xlen;
-    }
-    for (int f = 0; f < 2; ++f) {                          // FNAME, FCOMMENT: zero-terminated
-        if (flg & (f == 0 ? 8 : 16)) {
-            const void *z = memchr(p, 0, (size_t)(in_end_ - p));
-            if (!z) { err_ = "gzip error: truncated stream"; return false; }
-            p = (const uint8_t *)z + 1;
-        }
-    }
-    if (flg & 2) {                                         // FHCRC
-        if (in_end_ - p < 2) { err_ = "gzip error: truncated stream"; return false; }
-        p += 2;
-    }
-    in_ = p;
-    bitbuf_ = 0; bitcnt_ = 0;
-    return true;
-}
-
 // canonical Huffman code -> decode table with per-prefix subtables
-bool GzipMemberDecoder::build(const uint8_t *lens, int nsyms, bool is_dist, uint32_t *table, int main_bits, int cap) {
+template <typename T>
+bool DeflateCore<T>::build(const uint8_t *lens, int nsyms, bool is_dist, uint32_t *table, int main_bits, int cap) {
     int count[16] = {0};
     for (int s = 0; s < nsyms; ++s) count[lens[s]]++;
     const int main_size = 1 << main_bits;
@@ -158,8 +145,9 @@ bool GzipMemberDecoder::build(const uint8_t *lens, int nsyms, bool is_dist, uint
 }
 
 // RFC 1951 block header: leaves state_ at kStored or kHuffman
-bool GzipMemberDecoder::read_block_header() {
-    if (!need_bits(3)) { err_ = "gzip error: truncated stream"; return false; }
+template <typename T>
+bool DeflateCore<T>::read_block_header() {
+    if (!need_bits(3)) { err_ = truncated(); return false; }
     last_block_ = (bitbuf_ & 1u) != 0;
     const uint32_t type = (uint32_t)(bitbuf_ >> 1) & 3u;
     bitbuf_ >>= 3; bitcnt_ -= 3;
@@ -169,7 +157,7 @@ bool GzipMemberDecoder::read_block_header() {
         bitbuf_ >>= drop; bitcnt_ -= drop;
         in_ -= bitcnt_ >> 3;
         bitbuf_ = 0; bitcnt_ = 0;
-        if (in_end_ - in_ < 4) { err_ = "gzip error: truncated stream"; return false; }
+        if (in_end_ - in_ < 4) { err_ = truncated(); return false; }
         const uint32_t len = (uint32_t)in_[0] | ((uint32_t)in_[1] << 8), nlen = (uint32_t)in_[2] | ((uint32_t)in_[3] << 8);
         if ((len ^ 0xFFFFu) != nlen) { err_ = "gzip error: invalid stored block lengths"; return false; }
         in_ += 4;
@@ -188,7 +176,7 @@ bool GzipMemberDecoder::read_block_header() {
         for (int i = 280; i < 288; ++i) lens[i] = 8;
         for (int i = 0; i < 32; ++i) lens[288 + i] = 5;
     } else {
-        if (!need_bits(14)) { err_ = "gzip error: truncated stream"; return false; }
+        if (!need_bits(14)) { err_ = truncated(); return false; }
         hlit = (int)(bitbuf_ & 31u) + 257;
         hdist = (int)((bitbuf_ >> 5) & 31u) + 1;
         const int hclen = (int)((bitbuf_ >> 10) & 15u) + 4;
@@ -196,7 +184,7 @@ bool GzipMemberDecoder::read_block_header() {
         if (hlit > 286 || hdist > 30) { err_ = "gzip error: too many length or distance symbols"; return false; }
         uint8_t cl[19] = {0};
         for (int i = 0; i < hclen; ++i) {
-            if (!need_bits(3)) { err_ = "gzip error: truncated stream"; return false; }
+            if (!need_bits(3)) { err_ = truncated(); return false; }
             cl[kClOrder[i]] = (uint8_t)(bitbuf_ & 7u);
             bitbuf_ >>= 3; bitcnt_ -= 3;
         }
@@ -228,7 +216,7 @@ bool GzipMemberDecoder::read_block_header() {
             const int nb = (int)(e & 0xFFu), sym = (int)(e >> 8);
             int extra = 0, rep_base = 0;
             if (sym == 16) { extra = 2; rep_base = 3; } else if (sym == 17) { extra = 3; rep_base = 3; } else if (sym == 18) { extra = 7; rep_base = 11; }
-            if (bitcnt_ < nb + extra) { err_ = "gzip error: truncated stream"; return false; }
+            if (bitcnt_ < nb + extra) { err_ = truncated(); return false; }
             bitbuf_ >>= nb; bitcnt_ -= nb;
             if (sym < 16) { lens[n++] = (uint8_t)sym; continue; }
             const int rep = rep_base + (int)(bitbuf_ & ((1u << extra) - 1u));
@@ -254,43 +242,48 @@ bool GzipMemberDecoder::read_block_header() {
     return true;
 }
 
-bool GzipMemberDecoder::finish_trailer() {
-    const int drop = bitcnt_ & 7;
-    bitbuf_ >>= drop; bitcnt_ -= drop;
-    in_ -= bitcnt_ >> 3;
-    bitbuf_ = 0; bitcnt_ = 0;
-    if (in_end_ - in_ < 8) { err_ = "gzip error: truncated stream"; return false; }
-    const uint32_t want_crc = (uint32_t)in_[0] | ((uint32_t)in_[1] << 8) | ((uint32_t)in_[2] << 16) | ((uint32_t)in_[3] << 24);
-    const uint32_t want_size = (uint32_t)in_[4] | ((uint32_t)in_[5] << 8) | ((uint32_t)in_[6] << 16) | ((uint32_t)in_[7] << 24);
-    in_ += 8;
-    if (want_crc != crc_) { err_ = "gzip error: incorrect data check"; return false; }
-    if (want_size != (uint32_t)total_out_) { err_ = "gzip error: incorrect length check"; return false; }
-    return true;
+// keep the last 32 KiB of text for matches that reach back from the next piece
+template <typename T>
+void DeflateCore<T>::keep_history(const T *out, size_t pos) {
+    if (pos >= kDeflateWindow) {
+        memcpy(hist_, out + pos - kDeflateWindow, kDeflateWindow * sizeof(T));
+        hist_len_ = kDeflateWindow;
+    } else if (pos) {
+        size_t keep = hist_len_;
+        if (keep > kDeflateWindow - pos) keep = kDeflateWindow - pos;
+        memmove(hist_, hist_ + hist_len_ - keep, keep * sizeof(T));
+        memcpy(hist_ + keep, out, pos * sizeof(T));
+        hist_len_ = keep + pos;
+    }
 }
 
-GzipMemberDecoder::Status GzipMemberDecoder::run(uint8_t *out, size_t cap, size_t *produced) {
+template <typename T>
+typename DeflateCore<T>::Status DeflateCore<T>::run(T *out, size_t cap, size_t *produced) {
     size_t pos = 0;
     Status result = kError;
     constexpr uint64_t lit_mask = (1u << kLitBits) - 1, dist_mask = (1u << kDistBits) - 1;
+    constexpr uint32_t kWordElems = 8 / sizeof(T);
 
-    // copy a match of `len` bytes from `dist` back; the source may start in the history of earlier pieces
+    // copy a match of `len` elements from `dist` back; the source may start in the history of earlier pieces
     auto copy_match = [&](uint32_t len, uint32_t dist) -> bool {
-        uint8_t *dst = out + pos;
+        T *dst = out + pos;
         if (dist > pos) {
-            const size_t back = dist - pos;                 // bytes before this piece
+            const size_t back = dist - pos;                 // elements before this piece
             if (back > hist_len_) return false;
             size_t i = 0;
             for (; i < len && i < back; ++i) dst[i] = hist_[hist_len_ - back + i];
-            const uint8_t *src = dst - dist;                // valid from index `back` on
+            const T *src = dst - dist;                      // valid from index `back` on
             for (; i < len; ++i) dst[i] = src[i];
-        } else if (dist >= 8) {
-            const uint8_t *src = dst - dist;
+        } else if (dist >= kWordElems) {
+            const T *src = dst - dist;
             uint32_t i = 0;
-            do { memcpy(dst + i, src + i, 8); i += 8; } while (i < len);      // may overshoot by up to 7 bytes (slack below)
+            do { memcpy(dst + i, src + i, 8); i += kWordElems; } while (i < len);      // may overshoot by up to 7 bytes (slack below)
         } else if (dist == 1) {
-            memset(dst, dst[-1], len);
+            const T v = dst[-1];
+            if (sizeof(T) == 1) memset(dst, (int)v, len);
+            else for (uint32_t i = 0; i < len; ++i) dst[i] = v;
         } else {
-            const uint8_t *src = dst - dist;
+            const T *src = dst - dist;
             for (uint32_t i = 0; i < len; ++i) dst[i] = src[i];
         }
         pos += len;
@@ -298,25 +291,21 @@ GzipMemberDecoder::Status GzipMemberDecoder::run(uint8_t *out, size_t cap, size_
     };
 
     for (;;) {
-        if (state_ == kGzipHeader) {
-            if (!parse_gzip_header()) break;
-            state_ = kBlockHeader;
-        } else if (state_ == kBlockHeader) {
+        if (state_ == kBlockHeader) {
+            if (bit_pos() >= stop_bit_) { result = kBoundary; break; }
             if (!read_block_header()) break;
+        } else if (state_ == kDone) {
+            result = kStreamEnd;
+            break;
         } else if (state_ == kStored) {
             size_t n = stored_left_;
             if (n > cap - pos) n = cap - pos;
-            if (n > (size_t)(in_end_ - in_)) { err_ = "gzip error: truncated stream"; break; }
-            memcpy(out + pos, in_, n);
+            if (n > (size_t)(in_end_ - in_)) { err_ = truncated(); break; }
+            if (sizeof(T) == 1) memcpy(out + pos, in_, n);
+            else for (size_t i = 0; i < n; ++i) out[pos + i] = (T)in_[i];
             in_ += n; pos += n; stored_left_ -= (uint32_t)n;
-            if (stored_left_ == 0) state_ = last_block_ ? kTrailer : kBlockHeader;
+            if (stored_left_ == 0) state_ = last_block_ ? kDone : kBlockHeader;
             else { result = kPieceFull; break; }
-        } else if (state_ == kTrailer) {
-            crc_ = crc32_update(crc_, out, pos);
-            total_out_ += pos;
-            *produced = pos;
-            if (!finish_trailer()) return kError;
-            return kMemberEnd;
         } else {
             // ---- Huffman block: fast loop while input and output have slack ----
             bool block_done = false, bad = false;
@@ -331,16 +320,16 @@ GzipMemberDecoder::Status GzipMemberDecoder::run(uint8_t *out, size_t cap, size_
                 }
                 bitbuf_ >>= (e & 0xFFu); bitcnt_ -= (int)(e & 0xFFu);
                 if (e & F_LIT) {
-                    out[pos++] = (uint8_t)(e >> 16);
+                    out[pos++] = (T)(e >> 16);
                     // up to two more literals from the bits already in hand (>= 41 left, direct entries take <= 11)
                     e = lit_[bitbuf_ & lit_mask];
                     if ((e & (F_LIT | F_SUB)) == F_LIT) {
                         bitbuf_ >>= (e & 0xFFu); bitcnt_ -= (int)(e & 0xFFu);
-                        out[pos++] = (uint8_t)(e >> 16);
+                        out[pos++] = (T)(e >> 16);
                         e = lit_[bitbuf_ & lit_mask];
                         if ((e & (F_LIT | F_SUB)) == F_LIT) {
                             bitbuf_ >>= (e & 0xFFu); bitcnt_ -= (int)(e & 0xFFu);
-                            out[pos++] = (uint8_t)(e >> 16);
+                            out[pos++] = (T)(e >> 16);
                         }
                     }
                     continue;
@@ -379,9 +368,9 @@ GzipMemberDecoder::Status GzipMemberDecoder::run(uint8_t *out, size_t cap, size_
                         e = lit_[(e >> 16) + (uint32_t)(bb & ((1u << ((e >> 8) & 15u)) - 1u))];
                     }
                     used += (int)(e & 0xFFu); bb >>= (e & 0xFFu);
-                    if (e & F_BAD) { err_ = "gzip error: invalid literal/length code"; goto out; }
-                    if (used > bitcnt_) { err_ = "gzip error: truncated stream"; goto out; }
-                    if (e & F_LIT) { bitbuf_ = bb; bitcnt_ -= used; out[pos++] = (uint8_t)(e >> 16); continue; }
+                    if (e & F_BAD) { err_ = used > bitcnt_ ? truncated() : "gzip error: invalid literal/length code"; goto out; }
+                    if (used > bitcnt_) { err_ = truncated(); goto out; }
+                    if (e & F_LIT) { bitbuf_ = bb; bitcnt_ -= used; out[pos++] = (T)(e >> 16); continue; }
                     if (e & F_EOB) { bitbuf_ = bb; bitcnt_ -= used; block_done = true; break; }
                     uint32_t xb = (e >> 8) & 15u;
                     const uint32_t len = (e >> 16) + (uint32_t)(bb & ((1u << xb) - 1u));
@@ -391,35 +380,89 @@ GzipMemberDecoder::Status GzipMemberDecoder::run(uint8_t *out, size_t cap, size_
                         bb >>= kDistBits; used += kDistBits;
                         d = dist_[(d >> 16) + (uint32_t)(bb & ((1u << ((d >> 8) & 15u)) - 1u))];
                     }
-                    if (d & F_BAD) { err_ = used > bitcnt_ ? "gzip error: truncated stream" : "gzip error: invalid distance code"; goto out; }
+                    if (d & F_BAD) { err_ = used > bitcnt_ ? truncated() : "gzip error: invalid distance code"; goto out; }
                     bb >>= (d & 0xFFu); used += (int)(d & 0xFFu);
                     xb = (d >> 8) & 15u;
                     const uint32_t dist = (d >> 16) + (uint32_t)(bb & ((1u << xb) - 1u));
                     bb >>= xb; used += (int)xb;
-                    if (used > bitcnt_) { err_ = "gzip error: truncated stream"; goto out; }
+                    if (used > bitcnt_) { err_ = truncated(); goto out; }
                     bitbuf_ = bb; bitcnt_ -= used;
                     if (!copy_match(len, dist)) { err_ = "gzip error: invalid distance too far back"; goto out; }
                 }
             }
-            state_ = last_block_ ? kTrailer : kBlockHeader;
+            state_ = last_block_ ? kDone : kBlockHeader;
         }
     }
 out:
-    crc_ = crc32_update(crc_, out, pos);
-    total_out_ += pos;
-    // keep the last 32 KiB of this member's text for matches that reach back from the next piece
-    if (pos >= kWindow) {
-        memcpy(hist_, out + pos - kWindow, kWindow);
-        hist_len_ = kWindow;
-    } else if (pos) {
-        size_t keep = hist_len_;
-        if (keep > kWindow - pos) keep = kWindow - pos;
-        memmove(hist_, hist_ + hist_len_ - keep, keep);
-        memcpy(hist_ + keep, out, pos);
-        hist_len_ = keep + pos;
-    }
+    keep_history(out, pos);
     *produced = pos;
     return result;
+}
+
+template class DeflateCore<uint8_t>;
+template class DeflateCore<uint16_t>;
+
+// ---- gzip member framing ---------------------------------------------------------------------------
+size_t GzipMemberDecoder::parse_header(const uint8_t *p0, const uint8_t *end, const char **err) {
+    const uint8_t *p = p0;
+    const char *trunc = DeflateCore<uint8_t>::truncated();
+    if (end - p < 10) { *err = trunc; return 0; }
+    if (p[0] != 0x1f || p[1] != 0x8b) { *err = "gzip error: invalid gzip header"; return 0; }
+    if (p[2] != 8) { *err = "gzip error: unknown compression method"; return 0; }
+    const uint8_t flg = p[3];
+    if (flg & 0xE0) { *err = "gzip error: unknown header flags set"; return 0; }
+    p += 10;
+    if (flg & 4) {                                         // FEXTRA
+        if (end - p < 2) { *err = trunc; return 0; }
+        const size_t xlen = (size_t)p[0] | ((size_t)p[1] << 8);
+        p += 2;
+        if ((size_t)(end - p) < xlen) { *err = trunc; return 0; }
+        p += xlen;
+    }
+    for (int f = 0; f < 2; ++f) {                          // FNAME, FCOMMENT: zero-terminated
+        if (flg & (f == 0 ? 8 : 16)) {
+            const void *z = memchr(p, 0, (size_t)(end - p));
+            if (!z) { *err = trunc; return 0; }
+            p = (const uint8_t *)z + 1;
+        }
+    }
+    if (flg & 2) {                                         // FHCRC
+        if (end - p < 2) { *err = trunc; return 0; }
+        p += 2;
+    }
+    return (size_t)(p - p0);
+}
+
+void GzipMemberDecoder::begin(const uint8_t *in, const uint8_t *in_end) {
+    in_ = in; in_end_ = in_end;
+    started_ = false;
+    crc_ = 0;
+    total_out_ = 0;
+    err_ = "";
+}
+
+GzipMemberDecoder::Status GzipMemberDecoder::run(uint8_t *out, size_t cap, size_t *produced) {
+    *produced = 0;
+    if (!started_) {
+        const size_t hdr = parse_header(in_, in_end_, &err_);
+        if (!hdr) return kError;
+        core_.begin(in_, in_end_, (uint64_t)hdr * 8u);
+        started_ = true;
+    }
+    const DeflateCore<uint8_t>::Status st = core_.run(out, cap, produced);
+    crc_ = crc32_update(crc_, out, *produced);
+    total_out_ += *produced;
+    if (st == DeflateCore<uint8_t>::kPieceFull) return kPieceFull;
+    if (st != DeflateCore<uint8_t>::kStreamEnd) { err_ = core_.error(); return kError; }
+    // trailer: CRC-32 and ISIZE at the next byte boundary
+    const uint8_t *t = in_ + (core_.bit_pos() + 7) / 8;
+    if (in_end_ - t < 8) { err_ = DeflateCore<uint8_t>::truncated(); return kError; }
+    const uint32_t want_crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+    const uint32_t want_size = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+    if (want_crc != crc_) { err_ = "gzip error: incorrect data check"; return kError; }
+    if (want_size != (uint32_t)total_out_) { err_ = "gzip error: incorrect length check"; return kError; }
+    in_ = t + 8;
+    return kMemberEnd;
 }
 
 }  // namespace vf
@@ -503,6 +546,10 @@ uint32_t crc32_tables(uint32_t crc, const uint8_t *buf, size_t len) {
 }
 
 }  // namespace
+
+uint32_t crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
+    return (uint32_t)::crc32_combine((uLong)crc_a, (uLong)crc_b, (z_off_t)len_b);
+}
 
 uint32_t crc32_update(uint32_t crc, const uint8_t *buf, size_t len) {
     static const bool has_clmul = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");

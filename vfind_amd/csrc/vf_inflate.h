@@ -1,62 +1,94 @@
-// vf_inflate.h -- streaming gzip member decoder for the FASTQ input path (vf_fastq.cpp).
+// vf_inflate.h -- deflate / gzip decoding for the FASTQ input path (vf_fastq.cpp).
 //
 // Stands where flate2's MultiGzDecoder stands in the reference (src/lib.rs:233): RFC 1952 member
 // framing around RFC 1951 deflate, CRC-32 and ISIZE verified.  Written for this reader's shape: the
 // whole compressed file is mapped (no input refills), output goes to large caller-owned pieces, and a
-// member may span many pieces (the last 32 KiB of text are kept as history between pieces).
+// stream may span many pieces (the last 32 KiB of text are kept as history between pieces).
 // Tables: 11-bit primary literal/length table and 8-bit primary distance table with per-prefix
 // subtables, 64-bit bit buffer refilled once per symbol group, word-wise match copies.
+//
+// DeflateCore<T> decodes blocks from any block boundary (bit position).  With T = uint8_t the text that
+// precedes the start must be known (set_history).  With T = uint16_t it need not be: the window is
+// filled with markers (256 + window index) and every symbol copied from it stays a marker, to be
+// replaced once the real window is known - that is what lets one long deflate stream be decoded by
+// several threads (vf_fastq.cpp, after Kerbiriou & Chikhi's pugz).
 #pragma once
 #include <cstddef>
 #include <cstdint>
 
 namespace vf {
 
-class GzipMemberDecoder {
+constexpr size_t kDeflateWindow = 32768;
+constexpr uint16_t kMarkerBase = 256;            // uint16_t symbols >= this are window references
+
+template <typename T>
+class DeflateCore {
 public:
     enum Status {
-        kPieceFull = 0,      // the output piece is (nearly) full: hand it over and call again with a fresh one
-        kMemberEnd = 1,      // one whole member decoded and verified; in_pos() is just past its trailer
-        kError = 2,          // corrupt or truncated stream: message in error()
+        kPieceFull = 0,      // the output piece is (nearly) full: call again with a fresh one
+        kBoundary = 1,       // stopped in front of a block header at or beyond the stop bit
+        kStreamEnd = 2,      // the final block has ended; bit_pos() is just past it
+        kError = 3,          // corrupt or truncated stream: message in error()
     };
+    // start in front of a block header at absolute bit position bit_pos of the mapped file [base, in_end)
+    void begin(const uint8_t *base, const uint8_t *in_end, uint64_t bit_pos);
+    void set_stop_bit(uint64_t b) { stop_bit_ = b; }
+    void set_history(const T *text, size_t n);                 // the n <= 32768 elements in front of the output
+    void fill_markers();                                        // T = uint16_t: unknown window
+    Status run(T *out, size_t cap, size_t *produced);          // cap >= 1024
+    uint64_t bit_pos() const { return (uint64_t)(in_ - base_) * 8u - (uint64_t)bitcnt_; }
+    const T *history(size_t *n) const { *n = hist_len_; return hist_; }
+    const char *error() const { return err_; }
+    static const char *truncated() { return "gzip error: truncated stream"; }
+
+private:
+    enum State { kBlockHeader, kStored, kHuffman, kDone };
+    static constexpr int kLitBits = 11, kDistBits = 8;
+    static constexpr int kLitTableSize = (1 << kLitBits) + 1400, kDistTableSize = (1 << kDistBits) + 800;
+
+    bool read_block_header();
+    bool build(const uint8_t *lens, int nsyms, bool is_dist, uint32_t *table, int main_bits, int cap);
+    bool need_bits(int n);
+    void keep_history(const T *out, size_t pos);
+
+    const uint8_t *base_ = nullptr, *in_ = nullptr, *in_end_ = nullptr;
+    uint64_t bitbuf_ = 0;
+    int bitcnt_ = 0;
+    uint64_t stop_bit_ = ~0ull;
+    State state_ = kBlockHeader;
+    bool last_block_ = false;
+    uint32_t stored_left_ = 0;
+    const char *err_ = "";
+    size_t hist_len_ = 0;
+    uint32_t lit_[kLitTableSize];
+    uint32_t dist_[kDistTableSize];
+    T hist_[kDeflateWindow];
+};
+
+class GzipMemberDecoder {
+public:
+    enum Status { kPieceFull = 0, kMemberEnd = 1, kError = 2 };
     // start decoding a member at `in` (must stay mapped); `in_end` = end of the file
     void begin(const uint8_t *in, const uint8_t *in_end);
     // decode into out[0..cap); *produced = bytes written.  cap must be at least 1024.
     Status run(uint8_t *out, size_t cap, size_t *produced);
     const uint8_t *in_pos() const { return in_; }
     const char *error() const { return err_; }
+    // RFC 1952 header at p: returns the offset of the deflate data, or 0 with *err set
+    static size_t parse_header(const uint8_t *p, const uint8_t *end, const char **err);
 
 private:
-    enum State { kGzipHeader, kBlockHeader, kStored, kHuffman, kTrailer };
-    static constexpr int kLitBits = 11, kDistBits = 8;
-    static constexpr int kLitTableSize = (1 << kLitBits) + 1400, kDistTableSize = (1 << kDistBits) + 800;
-    static constexpr size_t kWindow = 32768;
-
-    bool parse_gzip_header();
-    bool read_block_header();
-    bool build(const uint8_t *lens, int nsyms, bool is_dist, uint32_t *table, int main_bits, int cap);
-    bool finish_trailer();
-    Status fail(const char *msg) { err_ = msg; return kError; }
-
-    // byte-precise bit input for headers and stream ends
-    bool need_bits(int n);
-
     const uint8_t *in_ = nullptr, *in_end_ = nullptr;
-    uint64_t bitbuf_ = 0;
-    int bitcnt_ = 0;
-    State state_ = kGzipHeader;
-    bool last_block_ = false;
-    uint32_t stored_left_ = 0;
+    bool started_ = false;
     uint32_t crc_ = 0;
     uint64_t total_out_ = 0;
     const char *err_ = "";
-    size_t hist_len_ = 0;
-    uint32_t lit_[kLitTableSize];
-    uint32_t dist_[kDistTableSize];
-    uint8_t hist_[kWindow];
+    DeflateCore<uint8_t> core_;
 };
 
 // CRC-32 (gzip polynomial) of buf[0..len), continuing from crc
 uint32_t crc32_update(uint32_t crc, const uint8_t *buf, size_t len);
+// CRC-32 of A followed by B from crc(A), crc(B) and len(B)
+uint32_t crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
 
 }  // namespace vf
