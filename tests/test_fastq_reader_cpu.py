@@ -20,12 +20,14 @@ def harness(tmp_path_factory):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "fastq_harness.cpp"),
                            os.path.join(ROOT, "vfind_amd", "csrc", "vf_fastq.cpp"),
-                           os.path.join(ROOT, "vfind_amd", "csrc", "vf_inflate.cpp"), "-o", exe, "-lz", "-lpthread"])
+                           os.path.join(ROOT, "vfind_amd", "csrc", "vf_inflate.cpp"),
+                           os.path.join(ROOT, "vfind_amd", "csrc", "vf_pinflate.cpp"), "-o", exe, "-lz", "-lpthread"])
     return exe
 
 
-def _run(exe, path, nt, timeout=120):
-    out = subprocess.run([exe, path, str(nt)], capture_output=True, text=True, timeout=timeout).stdout
+def _run(exe, path, nt, timeout=120, env=None):
+    out = subprocess.run([exe, path, str(nt)], capture_output=True, text=True, timeout=timeout,
+                         env=None if env is None else dict(os.environ, **env)).stdout
     return json.loads(out.strip().splitlines()[-1])
 
 
@@ -123,3 +125,37 @@ def test_reader_errors(harness, tmp_path):
     p = str(tmp_path / "empty.gz")
     open(p, "wb").write(gzip.compress(b""))
     assert _run(harness, p, 2) == {"rc": 0, "reads": 0, "bases": 0, "checksum": 0, "error": ""}
+
+
+def test_reader_members_decoded_by_all_threads(harness, tmp_path):
+    """the big-member regime (an ordinary single-member .fastq.gz): every member goes through
+    inflate_member_parallel; tiny cells so that a 20 MB text spans hundreds of them, on the same container
+    shapes as above, and corrupt / truncated streams still end in an error"""
+    reads = synth.make_reads(6, 50000, AD20, L=150, vary_len=True)
+    want = _expect(reads)
+    text = synth.fastq_text(reads)
+    files = {}
+    p = str(tmp_path / "single6.gz"); open(p, "wb").write(gzip.compress(text, 6)); files["single -6"] = p
+    p = str(tmp_path / "single1.gz"); open(p, "wb").write(gzip.compress(text, 1)); files["single -1"] = p
+    p = str(tmp_path / "stored.gz"); open(p, "wb").write(gzip.compress(text, 0)); files["stored blocks only"] = p
+    p = str(tmp_path / "three.gz"); synth.write_fastq_gz(p, reads, members=3); files["3 members"] = p
+    p = str(tmp_path / "nonl.gz"); open(p, "wb").write(gzip.compress(text[:-1], 9)); files["no final newline"] = p
+    for cell in ("4096", "30000", "1048576"):
+        env = {"VFIND_INFLATE_PARALLEL": "1", "VFIND_PINFLATE_CELL": cell}
+        for name, path in files.items():
+            for nt in (1, 3, 8):
+                assert _run(harness, path, nt, env=env) == want, (name, nt, cell)
+    env = {"VFIND_INFLATE_PARALLEL": "1", "VFIND_PINFLATE_CELL": "8192"}
+    blob = gzip.compress(text, 6)
+    bad = {
+        "truncated": blob[: len(blob) // 2],
+        "garbage": blob + b"trailing bytes that are not gzip........",
+        "crc": blob[:-6] + bytes([blob[-6] ^ 1]) + blob[-5:],
+        "flip": blob[:400_000] + bytes([blob[400_000] ^ 0x10]) + blob[400_001:],
+    }
+    for name, data in bad.items():
+        p = str(tmp_path / (name + ".gz"))
+        open(p, "wb").write(data)
+        for nt in (3, 8):
+            r = _run(harness, p, nt, env=env)
+            assert r["rc"] == 3 and "gzip" in r["error"], (name, nt, r)

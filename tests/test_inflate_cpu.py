@@ -17,14 +17,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def harness(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("inflate") / "inflate_harness")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", out,
-                           os.path.join(ROOT, "tests/cpp/inflate_harness.cpp"), os.path.join(ROOT, "vfind_amd/csrc/vf_inflate.cpp"), "-lz"])
+                           os.path.join(ROOT, "tests/cpp/inflate_harness.cpp"), os.path.join(ROOT, "vfind_amd/csrc/vf_inflate.cpp"),
+                           os.path.join(ROOT, "vfind_amd/csrc/vf_pinflate.cpp"), "-lz", "-lpthread"])
     return out
 
 
-def _run(harness, tmp_path, blob, piece):
+def _run(harness, tmp_path, blob, piece, threads=0, cell=None):
     src, dst = tmp_path / "in.gz", tmp_path / "out.bin"
     src.write_bytes(blob)
-    p = subprocess.run([harness, str(src), str(dst), str(piece)], capture_output=True, text=True, timeout=120)
+    env = dict(os.environ, VFIND_PINFLATE_CELL=str(cell)) if cell else None
+    p = subprocess.run([harness, str(src), str(dst), str(piece), "1", str(threads)], capture_output=True, text=True, timeout=120, env=env)
     return p.returncode, (dst.read_bytes() if p.returncode == 0 else b""), p.stderr
 
 
@@ -127,3 +129,37 @@ def test_crc32_matches_zlib(harness, tmp_path):
         for piece in (1024, 1031):
             rc, got, err = _run(harness, tmp_path, _member(data, 0), piece)
             assert rc == 0 and got == data, err
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("cell,threads", [(4096, 3), (20_000, 2), (1 << 20, 4)])
+def test_parallel_member_decoder_like_zlib(harness, tmp_path, name, cell, threads):
+    """inflate_member_parallel: marker-mode cells, chain check, marker resolution; cells far smaller than a
+    deflate block (most claims fail and the coordinator decodes itself) up to larger than the input"""
+    blob, want = CASES[name]
+    rc, got, err = _run(harness, tmp_path, blob, 70_000, threads=threads, cell=cell)
+    assert rc == 0, err
+    assert got == want
+
+
+def test_parallel_member_decoder_reports_corruption(harness, tmp_path):
+    rng = np.random.default_rng(13)
+    blob, want = CASES["fastq_l6"]
+    n_err = 0
+    for trial in range(60):
+        b = bytearray(blob)
+        kind = trial % 3
+        if kind == 0:
+            b[int(rng.integers(10, len(b) - 8))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            b = b[: int(rng.integers(1, len(b) - 1))]
+        else:
+            b[len(b) - 1 - int(rng.integers(0, 8))] ^= 0x40
+        rc, got, err = _run(harness, tmp_path, bytes(b), 70_000, threads=3, cell=8192)
+        assert rc in (0, 3), err
+        if rc == 0:
+            assert got == want
+        else:
+            assert "gzip error" in err
+            n_err += 1
+    assert n_err > 50

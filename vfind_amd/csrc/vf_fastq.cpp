@@ -19,15 +19,13 @@
 #include "../../include/vfind_hip.h"
 #include "vf_internal.h"
 #include "vf_inflate.h"
+#include "vf_pinflate.h"
 
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
-#if defined(__SSE2__)
-#include <emmintrin.h>
-#endif
 
 #include <algorithm>
 #include <atomic>
@@ -75,23 +73,9 @@ struct BufPool {
 
 struct Piece { uint8_t *data = nullptr; size_t size = 0; size_t nl = 0; };      // nl = newlines, counted by the inflate worker
 
-// newline count of a piece (SSE2: 16 bytes a step; the inflate workers run it in parallel while the
-// text is still in their caches, so the one sequencer thread never scans text itself)
-static size_t count_newlines(const uint8_t *p, size_t n) {
-    size_t c = 0, i = 0;
-#if defined(__SSE2__)
-    const __m128i nlv = _mm_set1_epi8('\n');
-    for (; i + 64 <= n; i += 64) {
-        const unsigned m0 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i)), nlv));
-        const unsigned m1 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i + 16)), nlv));
-        const unsigned m2 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i + 32)), nlv));
-        const unsigned m3 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i + 48)), nlv));
-        c += (size_t)__builtin_popcountll((uint64_t)m0 | ((uint64_t)m1 << 16) | ((uint64_t)m2 << 32) | ((uint64_t)m3 << 48));
-    }
-#endif
-    for (; i < n; ++i) c += p[i] == '\n';
-    return c;
-}
+// newline count of a piece: the inflate workers run it in parallel while the text is still in their
+// caches, so the one sequencer thread never scans text itself
+static size_t count_newlines(const uint8_t *p, size_t n) { return vf::count_byte(p, n, '\n'); }
 
 struct Task {
     uint64_t start = 0, end = 0;
@@ -155,6 +139,8 @@ struct Reader {
     size_t total_buffered = 0;                 // decoded text waiting in all tasks
     BufPool pieces{kPiece};
     bool stop = false;
+    bool big_members = false;                  // few, large members: one task at a time, each member decoded by all threads
+    uint32_t par_threads = 1;
 
     bool is_member_start(uint64_t off) const {
         return off + 18 <= size && file[off] == 0x1f && file[off + 1] == 0x8b && file[off + 2] == 8 && (file[off + 3] & 0xE0) == 0;
@@ -211,6 +197,46 @@ static void run_task(Reader &R, const std::shared_ptr<Task> &t) {
     bool ok = true;
     std::string err;
     uint64_t end = 0;
+    if (R.big_members) {
+        // one long deflate stream: every member is decoded by all threads (vf_pinflate.cpp)
+        R.pieces.put(piece.data);
+        piece = Piece();
+        vf::ParallelInflateIO io;
+        io.piece_bytes = kPiece;
+        io.get_buffer = [&R]() { return R.pieces.get(); };
+        io.drop_buffer = [&R](uint8_t *b) { R.pieces.put(b); };
+        io.progress = [&t](uint64_t off) { t->in_pos.store(off, std::memory_order_relaxed); };
+        uint64_t member = t->start;
+        io.put_piece = [&](uint8_t *b, size_t n, size_t nl) -> bool {
+            std::unique_lock<std::mutex> lk(R.mu);
+            Piece pc; pc.data = b; pc.size = n; pc.nl = nl;
+            t->buffered += n;
+            R.total_buffered += n;
+            t->out.push_back(pc);
+            R.cv.notify_all();
+            // the sequencer drains this task as it goes; keep at most 512 MiB of text ahead of it
+            R.cv.wait(lk, [&] { return t->abort || R.stop || t->buffered <= ((size_t)512 << 20); });
+            return !(t->abort || R.stop);
+        };
+        for (;;) {
+            const uint8_t *mend = nullptr;
+            const char *perr = "";
+            io.progress = [&t, member](uint64_t off) { t->in_pos.store(member + off, std::memory_order_relaxed); };
+            if (!vf::inflate_member_parallel(R.file + member, file_end, R.par_threads, io, &mend, &perr)) { ok = false; err = perr; break; }
+            const uint64_t e = (uint64_t)(mend - R.file);
+            t->in_pos.store(e, std::memory_order_relaxed);
+            if (e >= R.size) { end = R.size; break; }
+            if (e >= stop_at && R.is_member_start(e)) { end = e; break; }
+            member = e;                                      // next member of the same task (or trailing garbage: header check)
+        }
+        std::lock_guard<std::mutex> g(R.mu);
+        t->failed = !ok;
+        t->err = err;
+        t->end = end;
+        t->done = true;
+        R.cv.notify_all();
+        return;
+    }
     for (;;) {
         if (kPiece - fill < 4096 && !flush_piece(false)) { ok = false; err = "aborted"; break; }
         size_t got = 0;
@@ -334,7 +360,7 @@ static void inflate_worker(Reader &R) {
                 if (R.required != kNone && !R.tasks.count(R.required)) {
                     start = R.required;                      // what the sequencer is blocked on
                     R.spec_last = start;                     // speculation restarts from a known-true boundary
-                } else if (R.spec_last != kNone && R.total_buffered < kTotalCap) {
+                } else if (!R.big_members && R.spec_last != kNone && R.total_buffered < kTotalCap) {
                     // speculative: first member-like magic at or after the next grid line
                     const uint64_t from = next_grid(R.spec_last);
                     if (from < R.size) {
@@ -438,6 +464,18 @@ extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
         return vf_internal_fail(VF_EFORMAT, std::string(path) + ": not a gzip file (the reference reads gzip FASTQ only)");
 
     const uint32_t nthreads = std::max<uint32_t>(1, vf_internal_threads(c));
+    {
+        // Few large members (an ordinary `gzip file.fastq`) or many small ones (bgzip, pigz -i, concatenations)?
+        // Member-level parallelism needs the latter; for the former each member is decoded by all threads.
+        // (A false magic inside compressed data turns up about once per 134 MB and does not change the picture.)
+        const uint64_t span = std::min<uint64_t>(R.size, 64ull << 20);
+        uint64_t n_starts = 0, from = 1;
+        while (from < span) { const uint64_t m = R.next_magic(from); if (m == kNone || m >= span) break; ++n_starts; from = m + 1; }
+        const char *e = getenv("VFIND_INFLATE_PARALLEL");
+        const int forced = e ? atoi(e) : -1;
+        R.par_threads = nthreads;
+        R.big_members = forced >= 0 ? forced != 0 : (nthreads >= 3 && R.size >= (8ull << 20) && span / (n_starts + 1) >= (24ull << 20));
+    }
     BoundedQueue<std::unique_ptr<Chunk>> chunks(std::max<size_t>(2, nthreads));
     BufPool chunk_pool(kChunkCap);
     std::atomic<bool> failed{false};

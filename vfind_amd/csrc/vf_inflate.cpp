@@ -45,7 +45,7 @@ void DeflateCore<T>::begin(const uint8_t *base, const uint8_t *in_end, uint64_t 
 template <typename T>
 void DeflateCore<T>::set_history(const T *text, size_t n) {
     if (n > kDeflateWindow) { text += n - kDeflateWindow; n = kDeflateWindow; }
-    memmove(hist_, text, n * sizeof(T));
+    if (n) memmove(hist_, text, n * sizeof(T));
     hist_len_ = n;
 }
 
@@ -71,16 +71,18 @@ bool DeflateCore<T>::build(const uint8_t *lens, int nsyms, bool is_dist, uint32_
     int count[16] = {0};
     for (int s = 0; s < nsyms; ++s) count[lens[s]]++;
     const int main_size = 1 << main_bits;
+    int left = 1, max_len = 0;
+    if (count[0] != nsyms) {                               // validate before any table is touched (cheap rejection)
+        for (int len = 1; len <= 15; ++len) {
+            left <<= 1;
+            left -= count[len];
+            if (left < 0) return false;                    // over-subscribed
+            if (count[len]) max_len = len;
+        }
+        if (left > 0 && max_len != 1) return false;        // incomplete (zlib accepts only a lone 1-bit code)
+    }
     for (int i = 0; i < main_size; ++i) table[i] = F_BAD | 1u;
     if (count[0] == nsyms) return true;                    // no codes at all: any use is an error
-    int left = 1, max_len = 0;
-    for (int len = 1; len <= 15; ++len) {
-        left <<= 1;
-        left -= count[len];
-        if (left < 0) return false;                        // over-subscribed
-        if (count[len]) max_len = len;
-    }
-    if (left > 0 && max_len != 1) return false;            // incomplete (zlib accepts only a lone 1-bit code)
     uint32_t first[16];
     uint32_t code = 0;
     count[0] = 0;
@@ -546,6 +548,20 @@ uint32_t crc32_tables(uint32_t crc, const uint8_t *buf, size_t len) {
 }
 
 }  // namespace
+
+size_t count_byte(const uint8_t *p, size_t n, uint8_t c) {
+    size_t k = 0, i = 0;
+    const __m128i cv = _mm_set1_epi8((char)c);
+    for (; i + 64 <= n; i += 64) {
+        const unsigned m0 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i)), cv));
+        const unsigned m1 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i + 16)), cv));
+        const unsigned m2 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i + 32)), cv));
+        const unsigned m3 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i + 48)), cv));
+        k += (size_t)__builtin_popcountll((uint64_t)m0 | ((uint64_t)m1 << 16) | ((uint64_t)m2 << 32) | ((uint64_t)m3 << 48));
+    }
+    for (; i < n; ++i) k += p[i] == c;
+    return k;
+}
 
 uint32_t crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
     return (uint32_t)::crc32_combine((uLong)crc_a, (uLong)crc_b, (z_off_t)len_b);

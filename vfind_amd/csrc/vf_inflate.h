@@ -86,6 +86,8 @@ private:
     DeflateCore<uint8_t> core_;
 };
 
+// occurrences of byte c in p[0..n) (SSE2: 64 bytes a step)
+size_t count_byte(const uint8_t *p, size_t n, uint8_t c);
 // CRC-32 (gzip polynomial) of buf[0..len), continuing from crc
 uint32_t crc32_update(uint32_t crc, const uint8_t *buf, size_t len);
 // CRC-32 of A followed by B from crc(A), crc(B) and len(B)
