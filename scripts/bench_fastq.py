@@ -12,6 +12,8 @@ ap.add_argument("--members", type=int, default=16)
 ap.add_argument("--out", default="/tmp/vf_bench.fq.gz")
 ap.add_argument("--threads", type=int, nargs="*", default=[1, 3, 8, 16])
 ap.add_argument("--check", action="store_true")
+ap.add_argument("--level", type=int, default=1, help="gzip level of the generated file")
+ap.add_argument("--random-quals", action="store_true", help="quality strings with Illumina-like binned scores instead of all F")
 a = ap.parse_args()
 
 ads = synth.adapters(0x5EED0003, 20)
@@ -20,6 +22,7 @@ if not os.path.exists(a.out) or os.path.getsize(a.out) == 0:
     t0 = time.time()
     per = (a.reads + a.members - 1) // a.members
     qual = b"F" * 150
+    qrng = np.random.default_rng(99)
     with open(a.out, "wb") as f:
         for m in range(a.members):
             lo, hi = m * per, min(a.reads, (m + 1) * per)
@@ -29,8 +32,9 @@ if not os.path.exists(a.out) or os.path.getsize(a.out) == 0:
             seqs = b.reshape(-1, 150)
             parts = []
             for i in range(hi - lo):
-                parts.append(b"@r%d\n" % (lo + i)); parts.append(seqs[i].tobytes()); parts.append(b"\n+\n"); parts.append(qual); parts.append(b"\n")
-            f.write(gzip.compress(b"".join(parts), compresslevel=1))
+                parts.append(b"@r%d\n" % (lo + i)); parts.append(seqs[i].tobytes()); parts.append(b"\n+\n")
+                parts.append(qrng.choice(np.frombuffer(b"FFFFFFFFFFFF::,#", np.uint8), 150).tobytes() if a.random_quals else qual); parts.append(b"\n")
+            f.write(gzip.compress(b"".join(parts), compresslevel=a.level))
     print(f"wrote {a.out}: {os.path.getsize(a.out)/1e6:.1f} MB gz, {a.reads} reads, {a.members} members in {time.time()-t0:.1f}s", flush=True)
 text_bytes = None
 for nt in a.threads:

@@ -9,8 +9,9 @@
 //   start (or EOF).  Task starts are claimed speculatively ("first gzip magic at or after the grid
 //   line"): exact for BGZF and for ordinary multi-member files; a claim that was wrong (magic bytes
 //   inside compressed data) is simply never consumed, and the sequencer requests the task it actually
-//   needs, so correctness never depends on the speculation.  A single-member file degenerates to one
-//   streaming task (deflate itself is sequential).
+//   needs, so correctness never depends on the speculation.  A file of few, large members (the usual
+//   `gzip reads.fastq`) is handled the other way round: one task at a time, each member decoded by all
+//   threads (vf_pinflate.cpp: cells of the stream decoded with an unknown window, then resolved).
 // * The sequencer consumes tasks in file order (a task is consumed only if it starts exactly where the
 //   previous one ended), counts newlines to cut the text into chunks of whole four-line records and
 //   hands them to the frame+pack workers, which call the batch submission path.
