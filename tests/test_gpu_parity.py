@@ -338,6 +338,30 @@ def test_fastq_parallel_member_decode(tmp_path):
         vfind_amd.find_variants(p, AD20)
 
 
+def test_fastq_single_member_decoded_by_all_threads(tmp_path, monkeypatch):
+    """an ordinary single-member .fastq.gz through the big-member regime (every member decoded by all threads,
+    vf_pinflate.cpp), forced on and with small cells so that this 40 MB text spans many of them"""
+    import gzip
+    import vfind_amd
+    monkeypatch.setenv("VFIND_INFLATE_PARALLEL", "1")
+    monkeypatch.setenv("VFIND_PINFLATE_CELL", "262144")
+    reads = synth.make_reads(84, 120000, AD20, L=150, sub=0.01, indel=0.002, n_variants=800)
+    want = oracle.count(reads, AD20)
+    text = synth.fastq_text(reads)
+    for level in (1, 6):
+        p = str(tmp_path / f"single{level}.fq.gz")
+        open(p, "wb").write(gzip.compress(text, level))
+        for nt in (3, 16):
+            with vfind_amd.Engine(AD20, n_threads=nt, table_slots=1 << 16) as e:
+                e.run_fastq(p)
+                assert e.finish_dict() == want, (level, nt)
+                assert e.stats()["reads"] == len(reads)
+    p = str(tmp_path / "cut.fq.gz")
+    open(p, "wb").write(gzip.compress(text, 6)[:2_000_000])
+    with pytest.raises(vfind_amd.VfindError, match="gzip"):
+        vfind_amd.find_variants(p, AD20, n_threads=8)
+
+
 def test_fastq_errors(tmp_path):
     import gzip
     import vfind_amd
