@@ -80,3 +80,32 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
                 txt = open(os.path.join(d, f), errors="replace").read()
                 assert "oracle" not in txt.replace("no CPU fallback", ""), f"{f} mentions the oracle"
+
+
+def test_pack_read_matches_a_plain_packer():
+    """vf_pack_read (SIMD on x86 with SSSE3 + BMI2, table loop otherwise): 2 bits per base, A0 C1 G2 T3, base k at
+    bits [2k, 2k+1] of the row, zero padded; any byte outside ACGT is reported (the read then takes the
+    byte-wise path)"""
+    import ctypes
+    import numpy as np
+    from vfind_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    for t in range(4000):
+        n = int(rng.integers(0, 161))
+        s = rng.choice(np.frombuffer(b"ACGT", np.uint8), n)
+        dirty = t % 5 == 0 and n > 0
+        if dirty:
+            s = s.copy()
+            s[rng.integers(0, n)] = rng.choice(np.frombuffer(b"NacgtRn.@U\x00\xff", np.uint8))
+        row = np.full(10, 0xDEADBEEF, np.uint32)
+        rc = L.vf_pack_read(s.ctypes.data if n else None, n, row.ctypes.data, 10)
+        if dirty:
+            assert rc == 1
+            continue
+        want = np.zeros(10, np.uint32)
+        for i, c in enumerate(s):
+            want[i // 16] |= np.uint32(code[int(c)] << (2 * (i % 16)))
+        assert rc == 0 and (row == want).all(), (t, n)
+    assert L.vf_pack_read(np.frombuffer(b"A" * 161, np.uint8).ctypes.data, 161, np.zeros(10, np.uint32).ctypes.data, 10) == 1

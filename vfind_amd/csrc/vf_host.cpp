@@ -48,53 +48,8 @@ static int fail(int code, const std::string &msg) {
 extern "C" const char *vf_last_error(void) { return g_err.c_str(); }
 extern "C" int vf_abi_version(void) { return VF_ABI_VERSION; }
 
-// ------------------------------------------------------------------------------------------------
-// packing
-// ------------------------------------------------------------------------------------------------
-static uint8_t g_code[256];
-static std::once_flag g_code_once;
-static void init_code() {
-    memset(g_code, 0xFF, sizeof(g_code));
-    g_code[(int)'A'] = 0; g_code[(int)'C'] = 1; g_code[(int)'G'] = 2; g_code[(int)'T'] = 3;
-}
-
-extern "C" uint32_t vf_row_dwords_for(uint32_t max_len) {
-    if (max_len <= 160) return 10;
-    if (max_len <= 320) return 20;
-    if (max_len <= 640) return 40;
-    return 0;
-}
-
-// 2-bit pack; returns 1 when a byte outside {A,C,G,T} is met (row content then undefined)
-extern "C" int vf_pack_read(const uint8_t *seq, uint32_t n, uint32_t *row, uint32_t row_dwords) {
-    std::call_once(g_code_once, init_code);
-    if (n > row_dwords * 16u) return 1;
-    uint32_t bad = 0;
-    uint32_t full = n / 16;
-    for (uint32_t w = 0; w < full; ++w) {
-        const uint8_t *p = seq + 16 * w;
-        uint32_t v = 0;
-        for (int k = 0; k < 16; ++k) {
-            const uint32_t c = g_code[p[k]];
-            bad |= c;
-            v |= (c & 3u) << (2 * k);
-        }
-        row[w] = v;
-    }
-    uint32_t w = full;
-    if (n % 16) {
-        const uint8_t *p = seq + 16 * w;
-        uint32_t v = 0;
-        for (uint32_t k = 0; k < n % 16; ++k) {
-            const uint32_t c = g_code[p[k]];
-            bad |= c;
-            v |= (c & 3u) << (2 * k);
-        }
-        row[w++] = v;
-    }
-    for (; w < row_dwords; ++w) row[w] = 0;
-    return (bad & 0x80u) ? 1 : 0;
-}
+// base code of an adapter letter (the adapter was checked to be ACGT-only before this is used)
+static inline uint32_t base_code(unsigned char ch) { return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 0xFFu; }
 
 // ------------------------------------------------------------------------------------------------
 // context
@@ -285,7 +240,7 @@ static bool pure_acgt(const std::string &s) {
 }
 static uint64_t pack_adapter(const std::string &s) {
     uint64_t v = 0;
-    for (size_t i = 0; i < s.size(); ++i) v |= (uint64_t)(g_code[(unsigned char)s[i]] & 3u) << (2 * i);
+    for (size_t i = 0; i < s.size(); ++i) v |= (uint64_t)(base_code((unsigned char)s[i]) & 3u) << (2 * i);
     return v;
 }
 // Largest number of unit edits (mismatch, read base vs gap, adapter base vs gap, unaligned adapter end
@@ -309,7 +264,7 @@ static void fill_dp(DpParams &d, const std::string &ad, int64_t T, const vf_ctx 
     d.pat = pack_adapter(ad);
     d.m = (uint32_t)ad.size();
     for (int k = 0; k < 4; ++k) d.eq[k] = 0;
-    for (size_t i = 0; i < ad.size(); ++i) d.eq[g_code[(unsigned char)ad[i]] & 3u] |= 1u << i;
+    for (size_t i = 0; i < ad.size(); ++i) d.eq[base_code((unsigned char)ad[i]) & 3u] |= 1u << i;
     d.T = (int32_t)std::max<int64_t>(std::min<int64_t>(T, INT32_MAX), INT32_MIN + 1);
     d.mismatch = c.mismatch;
     const int32_t S = 1 << kScoreShift, P = 1 << kPrefShift;
@@ -341,7 +296,6 @@ static int table_clear_locked(vf_ctx *c, bool all_counters = false) {
 }
 
 extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
-    std::call_once(g_code_once, init_code);
     if (!p || !out) return fail(VF_EINVAL, "null argument");
     *out = nullptr;
     if ((p->prefix_len && !p->prefix) || (p->suffix_len && !p->suffix)) return fail(VF_EINVAL, "null adapter");
