@@ -579,18 +579,23 @@ static int run_packed(vf_ctx *c, hipStream_t st, Lane &lane, uint32_t chunk_row,
         const DpParams &dp = role == 0 ? dpP : dpS;
         if (c->filter_on) {
             // The five consumers of the filter's lists (four window classes + the full-width rest) are
-            // independent; only the first class is big.  The four small, latency-bound ones run back to
-            // back on the lane's side stream, next to the big one (one side stream per lane: the device
-            // exposes four hardware queues, more streams than that alias and serialise).
+            // independent.  The two shortest-window classes - where nearly all tasks are, which of the two
+            // depends on the adapter length - run back to back on the lane's stream; the long-window class, the
+            // two-window class and the full-width rest (a handful of tasks, but one wave's latency of a whole
+            // read) run beside them on the lane's side stream (one side stream per lane: the device exposes
+            // four hardware queues, more streams than that alias and serialise).
             { Timed t(c, st, K_FILTER); HIP_TRY(launch_filter(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters)); }
             HIP_TRY(hipEventRecord(lane.fork, st));
             hipStream_t side = lane.side[0];
             HIP_TRY(hipStreamWaitEvent(side, lane.fork, 0));
-            { Timed t(c, st, K_DPW); HIP_TRY(launch_dp_window(st, 0, W, d_rows, d_lens, dp, d_spans, bl)); }      // the big class
+            {
+                Timed t(c, st, K_DPW);
+                for (int q = 0; q < 2; ++q) HIP_TRY(launch_dp_window(st, q, W, d_rows, d_lens, dp, d_spans, bl));
+            }
             {
                 Timed t(c, side, K_DPREST);
-                for (int q = 1; q < 4; ++q) HIP_TRY(launch_dp_window(side, q, W, d_rows, d_lens, dp, d_spans, bl));
                 HIP_TRY(launch_dp(side, W, d_rows, d_lens, dp, d_spans, bl, true, c->tab.counters));
+                for (int q = 2; q < 4; ++q) HIP_TRY(launch_dp_window(side, q, W, d_rows, d_lens, dp, d_spans, bl));
             }
             HIP_TRY(hipEventRecord(lane.join[0], side));
             HIP_TRY(hipStreamWaitEvent(st, lane.join[0], 0));
