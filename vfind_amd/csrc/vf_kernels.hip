@@ -3,14 +3,18 @@
 // One read per lane, 64-lane waves, integer VALU only (no MFMA: there is no dense contraction in
 // this path).  Reference semantics being replaced (vfind 0.3.1, src/lib.rs):
 //   k_scan     memmem::find for both adapters (lib.rs:148) + the control flow of
-//              find_adapter_match (lib.rs:141-166); compacts reads that need the DP by wave ballot
-//   k_dp       parasail sg_stats_scan semi-global affine DP with the `length` statistic
-//              (lib.rs:155-160), tie policy P of SURVEY.md App. B.3
+//              find_adapter_match (lib.rs:141-166): eight pattern bases at every start position, the
+//              whole pattern at the survivors; appends reads that need an alignment to per-workgroup lists
+//   k_filter   exact pre-filter of those reads: Myers bit-vector edit distance of the adapter against
+//              every column -> the DP windows that can hold an accepted alignment
+//   k_dpw/k_dp parasail sg_stats_scan semi-global affine DP with the `length` statistic
+//              (lib.rs:155-160), tie policy P of SURVEY.md App. B.3, over the windows / the whole read
 //   k_finish   seq[start..end] extraction (lib.rs:288-290), translate (lib.rs:16-44) and the
-//              HashMap<String,u64> reduce (lib.rs:292-306) as a device hash-count table
+//              HashMap<String,u64> reduce (lib.rs:292-306) as a device hash-count table: one-shot lookup,
+//              dense insert list, counts in per-XCD arrays
 //   k_generic  the same per-read function byte-wise, for reads/adapters the 2-bit fast path
 //              cannot hold (non-ACGT bytes, adapters > 32 bp, reads > 640 bp, exotic scores)
-//   k_export / k_merge   table compaction and (key,count) merge for the multi-GPU exchange
+//   k_export / k_merge / k_rehash   table compaction, (key,count) merge for the multi-GPU exchange, growth
 #include "vf_device.h"
 
 #include <cstdlib>
