@@ -1,7 +1,7 @@
 """End-to-end timing of vf_run_fastq (gzip FASTQ -> table): BASELINE configs[2]-style input at a
 reduced read count.  Writes a multi-member gzip FASTQ of synthetic reads, then times the whole call."""
 import argparse, gzip, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import vfind_amd
 from vfind_amd import synth

@@ -2,7 +2,7 @@
 switch the Myers filter off or leave the 2-bit path), thresholds, read lengths and error rates; per-read spans and the
 (sequence,count) table from the device path must equal the CPU oracle's.  usage: fuzz_parity.py [iterations] [seed]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import vfind_amd
 from oracle import oracle

@@ -1,6 +1,6 @@
 """stress: parallel FASTQ reader (16 threads) + table growth from a tiny table under concurrent submitters"""
 import os, sys, time, gzip
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import vfind_amd
 from vfind_amd import synth
 from oracle import oracle
