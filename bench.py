@@ -228,7 +228,7 @@ def main():
             "finish": (st["ms_finish"], st["launches_finish"], n * 4 + st["accepted"] / steps * (row_b + 2)),
         }
         # dominant kernel = most device time among the kinds that are one kernel per launch (dp_rest brackets the
-        # side stream's group of small window classes + the full-width rest, not a single kernel)
+        # second window class and the side stream's group of kernels, not a single kernel)
         dom = max((k for k in kern if k != "dp_rest"), key=lambda k: kern[k][0])
         ms_tot, launches, bytes_per_launch = kern[dom]
         avg_ms = ms_tot / max(launches, 1)

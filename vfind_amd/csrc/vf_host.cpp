@@ -588,10 +588,8 @@ static int run_packed(vf_ctx *c, hipStream_t st, Lane &lane, uint32_t chunk_row,
             HIP_TRY(hipEventRecord(lane.fork, st));
             hipStream_t side = lane.side[0];
             HIP_TRY(hipStreamWaitEvent(side, lane.fork, 0));
-            {
-                Timed t(c, st, K_DPW);
-                for (int q = 0; q < 2; ++q) HIP_TRY(launch_dp_window(st, q, W, d_rows, d_lens, dp, d_spans, bl));
-            }
+            { Timed t(c, st, K_DPW); HIP_TRY(launch_dp_window(st, 0, W, d_rows, d_lens, dp, d_spans, bl)); }       // one kernel: the roofline line's unit
+            { Timed t(c, st, K_DPREST); HIP_TRY(launch_dp_window(st, 1, W, d_rows, d_lens, dp, d_spans, bl)); }
             {
                 Timed t(c, side, K_DPREST);
                 HIP_TRY(launch_dp(side, W, d_rows, d_lens, dp, d_spans, bl, true, c->tab.counters));
