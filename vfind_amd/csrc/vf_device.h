@@ -120,6 +120,12 @@ hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint1
 hipError_t launch_generic(hipStream_t s, const uint8_t *bytes, const uint64_t *offs, uint64_t n,
                           const GenericParams &gp, int32_t *starts, int32_t *ends, int32_t *ws,
                           uint64_t ws_stride, uint32_t ws_rows, Table t);
+hipError_t launch_generic_indexed(hipStream_t s, const uint8_t *text, const uint32_t *idx_start, const uint32_t *idx_len,
+                                  const uint32_t *n_dev, const GenericParams &gp, int32_t *ws, uint64_t ws_stride, uint32_t ws_rows, Table t);
+hipError_t launch_line_index(hipStream_t s, const uint8_t *text, uint64_t n, uint32_t *tile_cnt, uint32_t *tile_off, uint32_t *line_end,
+                             uint32_t *info);
+hipError_t launch_frame_pack(hipStream_t s, int W, const uint8_t *text, const uint32_t *line_end, uint32_t n_rec, uint32_t *rows,
+                             uint16_t *lens, uint32_t *gen_start, uint32_t *gen_len, uint32_t *info, bool all_generic);
 hipError_t launch_export(hipStream_t s, Table t, uint64_t *out_refs, uint64_t *out_counts, uint32_t *out_arena);
 hipError_t launch_rehash(hipStream_t s, Table from, Table to);
 hipError_t launch_merge(hipStream_t s, Table t, const uint64_t *refs, const uint64_t *counts,

@@ -63,10 +63,17 @@ struct BufPool {
     std::mutex mu;
     std::vector<uint8_t *> free_list;
     size_t bytes;
+    bool pinned = false;                       // page-locked buffers (device framing: text goes to the GPU straight from the pieces)
     explicit BufPool(size_t b) : bytes(b) {}
-    ~BufPool() { for (auto *p : free_list) free(p); }
+    std::vector<uint8_t *> locked;             // the page-locked ones (an allocation that fails falls back to malloc)
+    bool is_locked(uint8_t *p) const { return std::find(locked.begin(), locked.end(), p) != locked.end(); }
+    ~BufPool() { for (auto *p : free_list) { if (is_locked(p)) vf_internal_free_pinned(p); else free(p); } }
     uint8_t *get() {
         { std::lock_guard<std::mutex> g(mu); if (!free_list.empty()) { uint8_t *p = free_list.back(); free_list.pop_back(); return p; } }
+        if (pinned) {
+            uint8_t *p = vf_internal_alloc_pinned(bytes);
+            if (p) { std::lock_guard<std::mutex> g(mu); locked.push_back(p); return p; }
+        }
         return (uint8_t *)malloc(bytes);
     }
     void put(uint8_t *p) { if (p) { std::lock_guard<std::mutex> g(mu); free_list.push_back(p); } }
@@ -95,7 +102,7 @@ struct PieceHold {
     ~PieceHold() { pool->put(data); }
 };
 struct Seg { std::shared_ptr<PieceHold> hold; const uint8_t *p = nullptr; size_t n = 0; };
-struct Chunk { std::vector<Seg> segs; size_t size = 0; };
+struct Chunk { std::vector<Seg> segs; size_t size = 0; bool final = false; };
 
 template <typename T> struct BoundedQueue {
     std::mutex mu;
@@ -489,12 +496,15 @@ extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
     };
 
     // ---- frame + pack workers -----------------------------------------------------------------
+    // line index, record framing and 2-bit packing run on the device by default (VFIND_FASTQ_DEVICE_FRAMING=0: on these threads)
+    const bool device_framing = vf_internal_device_framing(c);
+    R.pieces.pinned = device_framing;
     std::vector<std::thread> packers;
     // n_threads inflate workers (the reference's n_threads are its alignment workers, next to one reader) and
     // half as many frame + pack workers, whose per-read work is lighter; the environment can override the split
     auto env_u = [](const char *k, uint32_t dflt) { const char *e = getenv(k); const int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : dflt; };
     const uint32_t ninfl = env_u("VFIND_FASTQ_INFLATERS", nthreads);
-    const uint32_t npack = env_u("VFIND_FASTQ_PACKERS", std::max<uint32_t>(1, (nthreads + 1) / 2));
+    const uint32_t npack = env_u("VFIND_FASTQ_PACKERS", device_framing ? std::max<uint32_t>(1, (nthreads + 3) / 4) : std::max<uint32_t>(1, (nthreads + 1) / 2));
     for (uint32_t w = 0; w < npack; ++w) {
         packers.emplace_back([&] {
             std::vector<ReadRef> refs;
@@ -503,12 +513,21 @@ extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
                 if (failed.load()) continue;
                 refs.clear();
                 std::string err;
+                int rc;
+                if (device_framing) {
+                    // the device indexes lines, frames records and packs (k_nl_*, k_frame_pack): the host only copies text
+                    std::vector<TextSpan> spans;
+                    for (auto &sg : ch->segs) spans.push_back(TextSpan{sg.p, sg.n});
+                    rc = vf_internal_submit_text(c, spans.data(), spans.size(), ch->final, R.pieces.pinned);
+                    ch->segs.clear();
+                    if (rc) err = vf_internal_last_error();
+                } else {
                 // the chunk's byte ranges -> one contiguous buffer (this copy used to sit on the sequencer thread)
                 uint8_t *text = chunk_pool.get();
                 size_t at = 0;
                 for (auto &sg : ch->segs) { memcpy(text + at, sg.p, sg.n); at += sg.n; }
                 ch->segs.clear();                            // pieces return to their pool
-                int rc = frame_records(text, at, refs, err);
+                rc = frame_records(text, at, refs, err);
                 if (!rc) {
                     if (g_dbg) fprintf(stderr, "[fastq] packer submits %zu reads at %.3f\n", refs.size(), now_s());
                     rc = vf_internal_submit(c, text, refs.data(), refs.size());
@@ -516,6 +535,7 @@ extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
                     if (rc) err = vf_internal_last_error();
                 }
                 chunk_pool.put(text);
+                }
                 if (rc) { fail_async(rc, err); break; }
             }
         });
@@ -582,6 +602,7 @@ extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
             if (cur->size == 0) { cur = std::move(next); lines = carried_lines; return true; }
         }
         if (g_dbg) fprintf(stderr, "[fastq] sequencer emits chunk of %zu bytes at %.3f\n", cur->size, now_s());
+        cur->final = final_flush;
         if (!chunks.put(std::move(cur))) return false;
         cur = std::move(next);
         lines = carried_lines;

@@ -161,6 +161,11 @@ struct Slot {
     PinBuf<int32_t> h_gstart, h_gend;
     PinBuf<short2> h_spans;
     std::vector<uint32_t> fast_idx, gen_idx;   // original positions (vf_spans_ascii)
+    // device framing of FASTQ text (vf_internal_submit_text)
+    PinBuf<uint8_t> h_text; DevBuf<uint8_t> d_text;
+    DevBuf<uint32_t> d_tile_cnt, d_tile_off, d_line_end, d_info, d_gen_start, d_gen_len;
+    PinBuf<uint32_t> h_info;
+    bool text_pending = false;   // h_info of the latest text batch has not been looked at yet
 };
 
 }  // namespace
@@ -407,6 +412,8 @@ extern "C" void vf_ctx_destroy(vf_ctx *c) {
         s->h_gbytes.release(); s->h_goffs.release(); s->d_gbytes.release(); s->d_goffs.release();
         s->d_gstart.release(); s->d_gend.release(); s->d_gws.release(); s->h_gstart.release(); s->h_gend.release();
         s->h_spans.release();
+        s->h_text.release(); s->d_text.release(); s->d_tile_cnt.release(); s->d_tile_off.release(); s->d_line_end.release();
+        s->d_info.release(); s->d_gen_start.release(); s->d_gen_len.release(); s->h_info.release();
         s->lane.destroy(); s->h_entries.release();
         if (s->done) (void)hipEventDestroy(s->done);
         if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -657,12 +664,33 @@ static void release_slot(vf_ctx *c, Slot *s) {
     { std::lock_guard<std::mutex> g(c->mu); s->busy = false; }
     c->cv.notify_one();
 }
-static int wait_slot(Slot *s) {
+static const char *fastq_error_text(uint32_t code) {
+    switch (code) {
+    case 1: return "malformed FASTQ: blank line inside the file";
+    case 2: return "malformed FASTQ: record does not start with '@'";
+    case 3: return "malformed FASTQ: missing '+' separator line";
+    case 4: return "malformed FASTQ: sequence and quality lengths differ";
+    default: return "malformed FASTQ";
+    }
+}
+// outcome of the slot's latest device-framed batch (its stream must have been waited for)
+static int collect_text_result(vf_ctx *c, Slot *s) {
+    if (!s->text_pending) return VF_OK;
+    s->text_pending = false;
+    c->n_generic += s->h_info.p[3];
+    const uint32_t e = s->h_info.p[2];
+    if (e != 0xFFFFFFFFu) {
+        vf_internal_set_async_error(c, VF_EFORMAT, fastq_error_text(e & 0xFFu));
+        return fail(VF_EFORMAT, fastq_error_text(e & 0xFFu));
+    }
+    return VF_OK;
+}
+static int wait_slot(vf_ctx *c, Slot *s) {
     if (s->in_flight) {
         HIP_TRY(hipEventSynchronize(s->done));
         s->in_flight = false;
     }
-    return VF_OK;
+    return collect_text_result(c, s);
 }
 
 // classify + pack one chunk into a slot and enqueue it.  spans_out != nullptr => synchronous,
@@ -674,7 +702,7 @@ static int submit_chunk(vf_ctx *c, const uint8_t *base, const ReadRef *reads, ui
     Slot *s = acquire_slot(c);
     struct Rel { vf_ctx *c; Slot *s; ~Rel() { release_slot(c, s); } } rel{c, s};
     int rc;
-    if ((rc = wait_slot(s))) return rc;
+    if ((rc = wait_slot(c, s))) return rc;
     CapacityTicket ticket{c};
     if (!spans_mode) {
         uint64_t need = 0;
@@ -817,7 +845,7 @@ extern "C" int vf_submit_packed(vf_ctx *c, const uint32_t *rows, uint32_t W, con
         Slot *s = acquire_slot(c);
         struct Rel { vf_ctx *c; Slot *s; ~Rel() { release_slot(c, s); } } rel{c, s};
         int rc;
-        if ((rc = wait_slot(s))) return rc;
+        if ((rc = wait_slot(c, s))) return rc;
         CapacityTicket ticket{c};
         uint64_t need = 0;
         for (uint64_t i = 0; i < m; ++i) need += arena_need(c, lens[lo + i]);
@@ -890,6 +918,7 @@ extern "C" int vf_sync(vf_ctx *c) {
         // a slot is only touched by its owner between acquire/release; here nobody may be submitting
         HIP_TRY(hipStreamSynchronize(s->stream));
         s->in_flight = false;
+        (void)collect_text_result(c, s.get());
     }
     for (auto &L : c->res) {
         if (!L.stream) continue;
@@ -898,6 +927,10 @@ extern "C" int vf_sync(vf_ctx *c) {
     }
     HIP_TRY(hipStreamSynchronize(c->main_stream));
     resolve_events(c);
+    {
+        std::lock_guard<std::mutex> g(c->err_mu);
+        if (c->async_rc) { int rc = c->async_rc; std::string m = c->async_msg; c->async_rc = 0; return fail(rc, m); }
+    }
     return check_device_errors(c, nullptr);
 }
 
@@ -1091,6 +1124,117 @@ extern "C" int vf_set_profiling(vf_ctx *c, int on) {
 // ------------------------------------------------------------------------------------------------
 // hooks for the FASTQ reader (vf_fastq.cpp)
 // ------------------------------------------------------------------------------------------------
+// A chunk of whole FASTQ records (byte ranges of inflated text): copied into pinned staging, sent to the
+// device, indexed by line, framed and packed there (k_nl_*, k_frame_pack), then the usual batch path.
+bool vf_internal_device_framing(const vf_ctx *) {
+    static const bool on = [] { const char *e = getenv("VFIND_FASTQ_DEVICE_FRAMING"); return !e || atoi(e) != 0; }();
+    return on;
+}
+uint8_t *vf_internal_alloc_pinned(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return (uint8_t *)p;
+}
+void vf_internal_free_pinned(uint8_t *p) { if (p) (void)hipHostFree(p); }
+
+int vf_internal_submit_text(vf_ctx *c, const TextSpan *spans, size_t n_spans, bool final_chunk, bool spans_pinned) {
+    size_t total = 0;
+    for (size_t i = 0; i < n_spans; ++i) total += spans[i].n;
+    if (total == 0) return VF_OK;
+    if (total > 0x7FFFFFF0ull) return fail(VF_EINVAL, "text chunk too large");
+    HIP_TRY(hipSetDevice(c->dev));
+    Slot *s = acquire_slot(c);
+    struct Rel { vf_ctx *c; Slot *s; ~Rel() { release_slot(c, s); } } rel{c, s};
+    int rc;
+    if ((rc = wait_slot(c, s))) return rc;
+    // final chunk: trailing newlines are padding, and the last record may lack its newline
+    size_t n_use = n_spans;
+    size_t last_n = n_spans ? spans[n_spans - 1].n : 0;
+    bool add_nl = false;
+    if (final_chunk) {
+        while (n_use) {
+            const uint8_t *p = spans[n_use - 1].p;
+            while (last_n && (p[last_n - 1] == '\n' || p[last_n - 1] == '\r')) { --last_n; --total; }
+            if (last_n) break;
+            --n_use;
+            last_n = n_use ? spans[n_use - 1].n : 0;
+        }
+        if (total == 0) return VF_OK;
+        add_nl = true;
+        ++total;
+    }
+    const size_t tiles = (total + 4095) / 4096;
+    if ((rc = s->d_text.ensure(total + 64))) return rc;
+    if ((rc = s->d_tile_cnt.ensure(tiles))) return rc;
+    if ((rc = s->d_tile_off.ensure(tiles))) return rc;
+    if ((rc = s->d_line_end.ensure(total + 1))) return rc;
+    if ((rc = s->d_info.ensure(4))) return rc;
+    if ((rc = s->h_info.ensure(4))) return rc;
+    if (spans_pinned) {
+        // the pieces are page-locked: the DMA engine reads them directly (they stay referenced until this call returns,
+        // and the stream is waited for below)
+        size_t at = 0;
+        for (size_t i = 0; i < n_use; ++i) {
+            const size_t n = i + 1 == n_use ? last_n : spans[i].n;
+            if (n) HIP_TRY(hipMemcpyAsync(s->d_text.p + at, spans[i].p, n, hipMemcpyHostToDevice, s->stream));
+            at += n;
+        }
+        if (add_nl) { static const uint8_t nl = '\n'; HIP_TRY(hipMemcpyAsync(s->d_text.p + at, &nl, 1, hipMemcpyHostToDevice, s->stream)); }
+    } else {
+        if ((rc = s->h_text.ensure(total + 64))) return rc;
+        size_t at = 0;
+        for (size_t i = 0; i < n_use; ++i) {
+            const size_t n = i + 1 == n_use ? last_n : spans[i].n;
+            memcpy(s->h_text.p + at, spans[i].p, n);
+            at += n;
+        }
+        if (add_nl) s->h_text.p[at] = '\n';
+        HIP_TRY(hipMemcpyAsync(s->d_text.p, s->h_text.p, total, hipMemcpyHostToDevice, s->stream));
+    }
+    HIP_TRY(launch_line_index(s->stream, s->d_text.p, total, s->d_tile_cnt.p, s->d_tile_off.p, s->d_line_end.p, s->d_info.p));
+    HIP_TRY(hipMemcpyAsync(s->h_info.p, s->d_info.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const uint32_t n_lines = s->h_info.p[0], max_line = s->h_info.p[1];
+    if (n_lines % 4u) return fail(VF_EFORMAT, "malformed FASTQ: truncated record");
+    const uint64_t n = n_lines / 4u;
+    if (n == 0) return VF_OK;
+    CapacityTicket ticket{c};
+    if ((rc = reserve_capacity(c, ticket, n, n * arena_need(c, max_line)))) return rc;
+    std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
+    uint32_t W = c->fast_ok ? vf_row_dwords_for(std::min<uint32_t>(std::max<uint32_t>(max_line, 1u), (uint32_t)kMaxFastRead)) : 10u;
+    if (W == 0) W = 40;
+    if ((rc = s->d_rows.ensure((size_t)n * W))) return rc;
+    if ((rc = s->d_lens.ensure(n))) return rc;
+    if ((rc = s->ws.ensure(n))) return rc;
+    if ((rc = s->d_gen_start.ensure(n))) return rc;
+    if ((rc = s->d_gen_len.ensure(n))) return rc;
+    // adapters / scores outside the 2-bit path: every read goes the byte-wise way (frame_pack lists reads longer than 0 rows)
+    HIP_TRY(launch_frame_pack(s->stream, c->fast_ok ? (int)W : 10, s->d_text.p, s->d_line_end.p, (uint32_t)n, s->d_rows.p, s->d_lens.p,
+                              s->d_gen_start.p, s->d_gen_len.p, s->d_info.p, !c->fast_ok));
+    c->n_reads += n;
+    if (c->fast_ok) {
+        if ((rc = run_packed(c, s->stream, s->lane, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, n, s->ws.spans.p, true, s->h_entries.p))) return rc;
+    }
+    {   // listed reads (non-ACGT bytes, longer than a row): byte-wise kernel over the same text, count known only on the device
+        const uint32_t mmax = (uint32_t)std::max(c->pre.size(), c->suf.size());
+        const uint32_t rows = 4 * mmax + (max_line + 3) / 4 + 4;
+        const uint64_t threads = 16384;
+        if ((rc = s->d_gws.ensure((size_t)rows * threads))) return rc;
+        GenericParams gp = c->gp;
+        gp.count_mode = 1;
+        Table tab = c->tab;
+        tab.chunk_row = s->index;
+        HIP_TRY(hipStreamWaitEvent(s->stream, c->clear_event, 0));
+        Timed t(c, s->stream, K_GEN);
+        HIP_TRY(launch_generic_indexed(s->stream, s->d_text.p, s->d_gen_start.p, s->d_gen_len.p, s->d_info.p + 3, gp, s->d_gws.p, threads, rows, tab));
+    }
+    HIP_TRY(hipMemcpyAsync(s->h_info.p, s->d_info.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipEventRecord(s->done, s->stream));
+    s->in_flight = true;
+    s->text_pending = true;
+    return VF_OK;
+}
+
 int vf_internal_submit(vf_ctx *c, const uint8_t *base, const ReadRef *reads, uint64_t n) {
     int rc = submit_reads(c, base, reads, n, nullptr, nullptr);
     return rc;

@@ -9,6 +9,14 @@ struct vf_ctx;
 struct ReadRef { uint64_t off; uint32_t len; };   // a sequence inside a text buffer
 
 int vf_internal_submit(vf_ctx *c, const uint8_t *base, const ReadRef *reads, uint64_t n);
+// a chunk of whole FASTQ records as byte ranges; framing and packing happen on the device
+struct TextSpan { const uint8_t *p; size_t n; };
+int vf_internal_submit_text(vf_ctx *c, const TextSpan *spans, size_t n_spans, bool final_chunk, bool spans_pinned);
+// whether text chunks are framed and packed on the device (default) or on the reader's threads
+bool vf_internal_device_framing(const vf_ctx *c);
+// page-locked host memory for the inflate pieces, so that text goes to the device straight from them
+uint8_t *vf_internal_alloc_pinned(size_t bytes);
+void vf_internal_free_pinned(uint8_t *p);
 void vf_internal_set_async_error(vf_ctx *c, int rc, const std::string &msg);
 uint32_t vf_internal_threads(const vf_ctx *c);
 int vf_internal_fail(int code, const std::string &msg);      // sets the calling thread's error text
