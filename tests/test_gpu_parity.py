@@ -362,6 +362,42 @@ def test_fastq_single_member_decoded_by_all_threads(tmp_path, monkeypatch):
         vfind_amd.find_variants(p, AD20, n_threads=8)
 
 
+def test_fastq_device_framing_edge_cases(tmp_path):
+    """records are framed and packed on the device: reads from 0 to 700 bases in one file (rows of 10, 20 and 40 words,
+    and longer ones that only the byte-wise kernel can hold), reads with N and lowercase letters, a last record
+    without its newline, trailing blank lines, and adapters the 2-bit path cannot hold at all (every read byte-wise)"""
+    import gzip
+    import vfind_amd
+    rng = np.random.default_rng(91)
+    reads = []
+    for L in (0, 1, 19, 40, 150, 151, 160, 161, 300, 320, 321, 639, 640, 641, 700):
+        reads += synth.make_reads(int(rng.integers(1, 1 << 30)), 60, AD20, L=max(L, 41), sub=0.02, indel=0.01, n_variants=20, dirty=0.1)
+        reads += [r[:L] for r in synth.make_reads(int(rng.integers(1, 1 << 30)), 10, AD20, L=max(L, 41), n_variants=5)]
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    text = synth.fastq_text(reads)
+    shapes = {"plain": text, "no final newline": text[:-1], "trailing blank lines": text + b"\n\n\r\n"}
+    want = oracle.count(reads, AD20)
+    for name, t in shapes.items():
+        p = str(tmp_path / (name.replace(" ", "_") + ".fq.gz"))
+        open(p, "wb").write(gzip.compress(t, 6))
+        with vfind_amd.Engine(AD20, n_threads=3, table_slots=1 << 14) as e:
+            e.run_fastq(p)
+            assert e.finish_dict() == want, name
+            st = e.stats()
+            assert st["reads"] == len(reads) and st["reads_generic"] > 0
+    odd = ("ACGTNACGTACGTACGTACG", "TTGACCAGTNNACGATTGCA")
+    p = str(tmp_path / "plain.fq.gz")
+    with vfind_amd.Engine(odd, n_threads=3, table_slots=1 << 14) as e:
+        e.run_fastq(p)
+        assert e.finish_dict() == oracle.count(reads, odd)
+    bad = str(tmp_path / "blank_inside.fq.gz")
+    k = text.index(b"\n@", len(text) // 2) + 1
+    open(bad, "wb").write(gzip.compress(text[:k] + b"\n" + text[k:], 6))
+    with pytest.raises(vfind_amd.VfindError, match="malformed FASTQ"):
+        vfind_amd.find_variants(bad, AD20)
+
+
 def test_fastq_errors(tmp_path):
     import gzip
     import vfind_amd

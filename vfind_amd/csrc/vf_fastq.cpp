@@ -1,7 +1,8 @@
 // vf_fastq.cpp -- gzip FASTQ input for vf_run_fastq (replaces File::open -> MultiGzDecoder -> Reader
 // -> parallel_fastq, src/lib.rs:233-234, 271-274).
 //
-//   [inflate pool] --text pieces--> [sequencer] --whole-record chunks--> [frame+pack pool] --> GPU
+//   [inflate pool] --text pieces--> [sequencer] --whole-record chunks--> [submit pool] --> GPU
+//   (the device indexes lines, frames records and packs; with VFIND_FASTQ_DEVICE_FRAMING=0 the submit pool does)
 //
 // * The compressed file is mmapped.  gzip members are independent deflate streams, so members are
 //   inflated in parallel (vf_inflate.cpp; VFIND_INFLATE=zlib selects zlib instead).  A decode task starts at a member start and runs through whole
