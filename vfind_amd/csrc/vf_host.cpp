@@ -1132,7 +1132,7 @@ bool vf_internal_device_framing(const vf_ctx *) {
 }
 uint8_t *vf_internal_alloc_pinned(size_t bytes) {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;      // any device of the process may read it
     return (uint8_t *)p;
 }
 void vf_internal_free_pinned(uint8_t *p) { if (p) (void)hipHostFree(p); }
