@@ -30,7 +30,7 @@ int vf_internal_submit(vf_ctx *, const uint8_t *base, const ReadRef *reads, uint
 }
 // device framing is a GPU path; the harness exercises the host framer
 bool vf_internal_device_framing(const vf_ctx *) { return false; }
-uint8_t *vf_internal_alloc_pinned(size_t n) { return (uint8_t *)malloc(n); }
+uint8_t *vf_internal_alloc_pinned(const vf_ctx *, size_t n) { return (uint8_t *)malloc(n); }
 void vf_internal_free_pinned(uint8_t *p) { free(p); }
 int vf_internal_submit_text(vf_ctx *, const TextSpan *, size_t, bool, bool) { t_err = "device framing is not available in the CPU harness"; return 4; }
 void vf_internal_set_async_error(vf_ctx *, int rc, const std::string &msg) {

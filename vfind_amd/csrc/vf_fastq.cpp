@@ -64,6 +64,7 @@ struct BufPool {
     std::mutex mu;
     std::vector<uint8_t *> free_list;
     size_t bytes;
+    const vf_ctx *ctx = nullptr;
     bool pinned = false;                       // page-locked buffers (device framing: text goes to the GPU straight from the pieces)
     explicit BufPool(size_t b) : bytes(b) {}
     std::vector<uint8_t *> locked;             // the page-locked ones (an allocation that fails falls back to malloc)
@@ -72,7 +73,7 @@ struct BufPool {
     uint8_t *get() {
         { std::lock_guard<std::mutex> g(mu); if (!free_list.empty()) { uint8_t *p = free_list.back(); free_list.pop_back(); return p; } }
         if (pinned) {
-            uint8_t *p = vf_internal_alloc_pinned(bytes);
+            uint8_t *p = vf_internal_alloc_pinned(ctx, bytes);
             if (p) { std::lock_guard<std::mutex> g(mu); locked.push_back(p); return p; }
         }
         return (uint8_t *)malloc(bytes);
@@ -499,6 +500,7 @@ extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
     // ---- frame + pack workers -----------------------------------------------------------------
     // line index, record framing and 2-bit packing run on the device by default (VFIND_FASTQ_DEVICE_FRAMING=0: on these threads)
     const bool device_framing = vf_internal_device_framing(c);
+    R.pieces.ctx = c;
     R.pieces.pinned = device_framing;
     std::vector<std::thread> packers;
     // n_threads inflate workers (the reference's n_threads are its alignment workers, next to one reader) and

@@ -1130,8 +1130,9 @@ bool vf_internal_device_framing(const vf_ctx *) {
     static const bool on = [] { const char *e = getenv("VFIND_FASTQ_DEVICE_FRAMING"); return !e || atoi(e) != 0; }();
     return on;
 }
-uint8_t *vf_internal_alloc_pinned(size_t bytes) {
+uint8_t *vf_internal_alloc_pinned(const vf_ctx *c, size_t bytes) {
     void *p = nullptr;
+    if (hipSetDevice(c->dev) != hipSuccess) return nullptr;      // called from reader threads: stay on the context's device
     if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;      // any device of the process may read it
     return (uint8_t *)p;
 }

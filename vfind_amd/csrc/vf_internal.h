@@ -15,7 +15,7 @@ int vf_internal_submit_text(vf_ctx *c, const TextSpan *spans, size_t n_spans, bo
 // whether text chunks are framed and packed on the device (default) or on the reader's threads
 bool vf_internal_device_framing(const vf_ctx *c);
 // page-locked host memory for the inflate pieces, so that text goes to the device straight from them
-uint8_t *vf_internal_alloc_pinned(size_t bytes);
+uint8_t *vf_internal_alloc_pinned(const vf_ctx *c, size_t bytes);
 void vf_internal_free_pinned(uint8_t *p);
 void vf_internal_set_async_error(vf_ctx *c, int rc, const std::string &msg);
 uint32_t vf_internal_threads(const vf_ctx *c);
