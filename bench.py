@@ -133,6 +133,11 @@ def main():
             cpu = {"value": round(sample / best / 1e6, 4), "unit": "M reads/s", "cores": cores, "kind": "port",
                    "sample": f"first {sample} reads of the same workload, all {cores} host threads, best of 2; "
                              "CPU restatement of vfind 0.3.1 (reference not buildable: no rustc/parasail)"}
+            # the reference's default worker count (n_threads = 3, lib.rs:178) on a tenth of that sample
+            s3 = max(probe_n, sample // 10)
+            tq = time.perf_counter()
+            oracle.count((sb[: s3 * L], so[: s3 + 1]), ads, n_threads=3)
+            cpu["at_reference_default_threads"] = {"value": round(s3 / max(time.perf_counter() - tq, 1e-4) / 1e6, 4), "cores": 3, "sample_reads": s3}
             del sb, so
         del pb, po
     eng.reset_stats()
