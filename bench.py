@@ -96,7 +96,8 @@ def main():
     torch.cuda.synchronize(dev)
 
     slots = args.table_slots or (1 << 16)
-    while not args.table_slots and slots < 2 * min(args.variants, n):       # load factor <= 0.5 at worst
+    # load factor <= 0.5 at worst: the library, plus room for the keys that differ only by an alignment-derived cut
+    while not args.table_slots and slots < max(2 * min(args.variants, n), n // 8):
         slots <<= 1
     eng = vfind_amd.Engine(ads, device=local_rank, table_slots=slots, arena_bytes=1 << 30)
 
