@@ -250,6 +250,44 @@ def test_filter_and_window_edge_cases():
         _check_spans(rd, AD20, accept_prefix_alignment=acc, accept_suffix_alignment=acc)
 
 
+def test_banded_class_single_edit_tasks():
+    """Tasks whose best end column has unit edit distance 1 take the banded DP (k_dpb, class 0 of the filter):
+    one substitution, one inserted or one deleted base at every adapter position, with the adapter at the read
+    start (band left of column 0), at the read end (last-column cells, every read length mod 4), overhanging
+    either end, and next to a second, worse copy; several scoring schemes and adapter lengths"""
+    rng = np.random.default_rng(77)
+    R = lambda k: synth.rand_seq(rng, k).decode()
+    other = lambda c: "ACGT"[("ACGT".index(c) + 1 + int(rng.integers(0, 3))) % 4]
+    for ads in (AD20, ("GATCGGAAGAGCACACGTCTGAACTCCAGT", "AGATCGGAAGAGCGTCGTGTAGGGAAAGAG"), ("ACGGTCA", "TTGCAAGC")):
+        P, S = ads
+        reads = []
+        for ad, is_p in ((P, True), (S, False)):
+            m = len(ad)
+            oth = S if is_p else P
+            for i in range(m):
+                for kind in range(3):
+                    e = ad[:i] + other(ad[i]) + ad[i + 1:] if kind == 0 else (ad[:i] + R(1) + ad[i:] if kind == 1 else ad[:i] + ad[i + 1:])
+                    for flank in (0, 1, 2, 3, 7):
+                        for tail in (0, 1, 2, 3, 5):
+                            body = R(flank) + e + R(tail) if not is_p else R(flank) + e + R(30 + tail) + oth
+                            if not is_p:
+                                body = oth + R(33) + body
+                            reads.append(body)
+                    reads.append(e[2:] + R(40) + oth if is_p else oth + R(40) + e[:-2])          # overhang + one edit
+            reads.append(R(3) + ad[:m // 2] + other(ad[m // 2]) + ad[m // 2 + 1:] + R(m + 9) + ad[:3] + other(ad[3]) + other(ad[4]) + ad[5:] + R(20))
+        reads = [r.encode() for r in reads]
+        for kw in (dict(), dict(accept_prefix_alignment=0.6, accept_suffix_alignment=0.9),
+                   dict(match_score=2, mismatch_score=-1, gap_open_penalty=3, gap_extend_penalty=1),
+                   dict(match_score=5, mismatch_score=-1, gap_open_penalty=5, gap_extend_penalty=2, accept_prefix_alignment=0.6, accept_suffix_alignment=0.6),
+                   dict(match_score=4, mismatch_score=-4, gap_open_penalty=8, gap_extend_penalty=4, accept_prefix_alignment=0.5, accept_suffix_alignment=0.5)):
+            _check_spans(reads, ads, **kw)
+    # random low-error libraries: most tasks are class 0; read lengths of every residue mod 16
+    for seed, L in ((301, 150), (302, 151), (303, 157), (304, 160), (305, 98)):
+        rd = synth.make_reads(seed, 4000, AD20, L=L, sub=0.02, indel=0.01, flank_max=9, vary_len=True)
+        _check_spans(rd, AD20)
+        _check_counts(rd, AD20)
+
+
 @pytest.mark.parametrize("name,kw", [
     ("cfg2", dict(seed=0x5EED0002, read_len=150, m=20, sub_rate=0.005, indel_rate=0.0005)),
     ("cfg4", dict(seed=0x5EED0004, read_len=150, m=20, sub_rate=0.15, indel_rate=0.0)),

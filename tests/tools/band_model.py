@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""CPU model of the filter's class-0 decision and of k_dpb's banded DP (vf_kernels.hip), checked against the
+full-matrix DP of oracle/pyref.py on random tasks.  No GPU: it restates the kernel's control flow (relative
+columns, rows per column, what a cell reads outside the band) in Python, so the argument of DESIGN.md 4.3
+(tightened edit bound, shrunk cluster, band of diagonals) is tested on its own.
+
+    python tests/tools/band_model.py [cases] [seed]
+"""
+import os
+import random
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from oracle import pyref  # noqa: E402  (test infrastructure)
+
+NEG = -(1 << 28)
+KBAND = 8
+
+
+def max_unit_errors(T, m, match, mismatch, gopen, gext):
+    L = match * m - T
+    if L < 0:
+        return -1
+    if match < 1 or match - mismatch < 1 or gext < 1 or gopen < 0:
+        return None
+    c_other = min(match, match - mismatch, min(gopen, gext) + match)
+    best = L // c_other
+    g = 1
+    while g * gopen <= L and g <= 4096:
+        ln = g
+        while g * gopen + (ln - g) * gext <= L:
+            best = max(best, ln + (L - g * gopen - (ln - g) * gext) // c_other)
+            ln += 1
+        g += 1
+    return best
+
+
+def myers_last_row(q, r):
+    m, n = len(q), len(r)
+    prev = list(range(m + 1))
+    out = [m]
+    for j in range(1, n + 1):
+        cur = [0] * (m + 1)
+        for i in range(1, m + 1):
+            cur[i] = min(prev[i - 1] + (q[i - 1] != r[j - 1]), prev[i] + 1, cur[i - 1] + 1)
+        out.append(cur[m])
+        prev = cur
+    return out
+
+
+def clusters(det_cols, gap):
+    ncl, c = 0, [0, 0, 0, 0]
+    for j in det_cols:
+        if ncl == 0:
+            ncl = 1; c[0] = c[1] = j
+        elif ncl == 1:
+            if j - c[1] > gap:
+                ncl = 2; c[2] = c[3] = j
+            else:
+                c[1] = j
+        elif ncl == 2:
+            if j - c[3] > gap:
+                ncl = 3
+            else:
+                c[3] = j
+    return ncl, c
+
+
+def banded(q, r, av, match, mismatch, gopen, gext):
+    """k_dpb restated: cells are (score, length); returns (score, length)"""
+    m, n = len(q), len(r)
+    KT = m + KBAND - 1
+    H = [(0, 0)] * m           # column 0 of the read
+    E = [(NEG, 0)] * m
+    k0 = 1 - av if av < 0 else 1
+    kend = min(KT, n - av)
+    best = (NEG, 0)
+    done = None
+    for k in range(1, KT + 1):
+        if not (k0 <= k <= kend):
+            continue
+        j = av + k
+        r0, r1 = max(1, k - KBAND + 1), min(m, k)
+        hup = (0, 0) if r0 == 1 else (NEG, 0)
+        f1 = (NEG, 0)
+        hdiag = (0, 0) if r0 == 1 else H[r0 - 2]
+        for row in range(r0, r1 + 1):
+            hc = (NEG, 0) if row == k else H[row - 1]
+            ec = (NEG, 0) if row == k else E[row - 1]
+            eo, ee = hc[0] - gopen, ec[0] - gext
+            e = (eo, hc[1] + 1) if eo > ee else (ee, ec[1] + 1)
+            fo, fe = hup[0] - gopen, f1[0] - gext
+            f = (fo, hup[1] + 1) if fo > fe else (fe, f1[1] + 1)
+            a, b = q[row - 1], r[j - 1]
+            d = (hdiag[0] + (match if a == b else mismatch), hdiag[1] + 1)
+            hs = max(d[0], e[0], f[0])
+            h = d if hs == d[0] else (f if hs == f[0] else e)
+            hdiag = hc
+            H[row - 1] = h
+            E[row - 1] = e
+            hup, f1 = h, f
+        if r1 == m and H[m - 1][0] > best[0]:
+            best = H[m - 1]
+        if j == n:
+            bs, bl = best
+            for row in range(r0, min(r1, m - 1) + 1):
+                if H[row - 1][0] > bs:
+                    bs, bl = H[row - 1]
+            done = (bs, bl)
+    return done if done is not None else best
+
+
+def one_case(rng):
+    match = rng.choice([1, 2, 3, 3, 3, 4, 5])
+    mismatch = rng.choice([-4, -3, -2, -2, -2, -1, 0])
+    gopen = rng.choice([0, 2, 3, 5, 5, 5, 8])
+    gext = rng.choice([1, 2, 2, 2, 3, 4])
+    m = rng.randint(4, 24)
+    acc = rng.choice([0.5, 0.6, 0.7, 0.75, 0.75, 0.8, 0.9])
+    T = int(acc * match * m // 1) + 1
+    ad = [rng.randrange(4) for _ in range(m)]
+    # read: flank + adapter with a few edits + tail, sometimes cut at either end
+    cp = list(ad)
+    for _ in range(rng.choice([1, 1, 1, 1, 2, 2, 3])):
+        t = rng.random()
+        p = rng.randrange(len(cp))
+        if t < 0.6:
+            cp[p] = (cp[p] + rng.randint(1, 3)) % 4
+        elif t < 0.8:
+            cp.insert(p, rng.randrange(4))
+        elif len(cp) > 2:
+            del cp[p]
+    flank = [rng.randrange(4) for _ in range(rng.choice([0, 0, 1, 2, 5, 9, 17]))]
+    tail = [rng.randrange(4) for _ in range(rng.choice([0, 0, 1, 2, 3, 7, 20]))]
+    read = flank + cp + tail
+    if rng.random() < 0.2:
+        read = read[rng.randint(1, 3):]
+    if rng.random() < 0.2:
+        read = read[: len(read) - rng.randint(1, 3)]
+    if rng.random() < 0.1:
+        read = read + [rng.randrange(4) for _ in range(5)] + cp
+    n = len(read)
+    if n == 0:
+        return None
+    kerr = max_unit_errors(T, m, match, mismatch, gopen, gext)
+    if kerr is None or kerr < 1 or m + kerr > 48:
+        return None
+    c_max = max(match, match - mismatch, match + max(gopen, gext))
+    T_lo = max(T, match * m - c_max)
+    k_lo = max_unit_errors(T_lo, m, match, mismatch, gopen, gext)
+    if k_lo is None or not (1 <= k_lo < kerr):
+        return None
+    D = myers_last_row(ad, read)
+    det = [j for j in range(1, n + 1) if D[j] <= kerr]
+    ncl, c = clusters(det, m + kerr)
+    own = 4 * (n // 4)
+    dmin = min(D[1: own + 1]) if own else m
+    if not (dmin <= 1 and ncl == 1):
+        return None
+    dl = kerr - k_lo
+    lo = c[0] + dl if c[0] > 1 else 1
+    hi = c[1] - dl if c[1] < n else n
+    if not (hi >= lo and hi - lo + 2 * k_lo + 1 <= KBAND):
+        return None
+    av = lo - m - k_lo
+    letters = b"ACGT"
+    qb = bytes(letters[x] for x in ad)
+    rb = bytes(letters[x] for x in read)
+    fs, fl, _, _ = pyref.sg_stats_py(qb, rb, match, mismatch, gopen, gext)
+    bs, bl = banded(ad, read, av, match, mismatch, gopen, gext)
+    ok_full, ok_band = fs >= T, bs >= T
+    good = ok_full == ok_band and (not ok_full or (fs == bs and fl == bl))
+    if not good:
+        print("MISMATCH", dict(match=match, mismatch=mismatch, gopen=gopen, gext=gext, T=T, kerr=kerr, k_lo=k_lo, av=av, lo=lo, hi=hi,
+                               cl=c, dmin=dmin), qb, rb, "full", (fs, fl), "band", (bs, bl))
+    return good
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    ran = bad = 0
+    while ran < cases:
+        g = one_case(rng)
+        if g is None:
+            continue
+        ran += 1
+        bad += not g
+    print(f"{ran} class-0 tasks, {bad} mismatches")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -36,6 +36,7 @@ struct DpParams {
     uint32_t is_prefix;
     uint32_t independent; // 1 = test hook: run the suffix DP even when the prefix failed (lib.rs:278-286)
     int32_t kerr;         // max unit edits of an acceptable alignment (pre-DP filter); <0 = none can pass
+    int32_t kerr_lo;      // the same bound for a task whose best end column has unit edit distance 1; <0 = not tighter
     uint32_t eq_top[4];   // eq[c] moved to the top m bits, low 32-m bits set (Myers filter)
     uint32_t pv_init;     // top m bits set
 };

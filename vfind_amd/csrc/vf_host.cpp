@@ -281,6 +281,17 @@ static void fill_dp(DpParams &d, const std::string &ad, int64_t T, const vf_ctx 
     d.is_prefix = is_prefix ? 1u : 0u;
     d.independent = 0;
     d.kerr = max_unit_errors(T, ad.size(), c.match, c.mismatch, c.gopen, c.gext);
+    // Tightened bound for tasks whose best end column has unit edit distance 1 (nearly all tasks of a
+    // low-error library): that alignment loses at most c_max against m matches, so the optimum scores
+    // >= match*m - c_max and every optimal alignment has at most kerr_lo unit edits.
+    d.kerr_lo = -1;
+    if (d.kerr >= 1 && d.kerr != INT32_MAX) {
+        const int64_t c_max = std::max<int64_t>(std::max<int64_t>(c.match, (int64_t)c.match - c.mismatch),
+                                                (int64_t)c.match + std::max(c.gopen, c.gext));
+        const int64_t T_lo = std::max<int64_t>(T, (int64_t)c.match * (int64_t)ad.size() - c_max);
+        const int32_t k_lo = max_unit_errors(T_lo, ad.size(), c.match, c.mismatch, c.gopen, c.gext);
+        if (k_lo >= 1 && k_lo < d.kerr) d.kerr_lo = k_lo;
+    }
     const uint32_t up = 32u - d.m;                     // d.m in 1..32
     for (int q = 0; q < 4; ++q) d.eq_top[q] = up ? ((d.eq[q] << up) | ((1u << up) - 1u)) : d.eq[q];
     d.pv_init = up ? (0xFFFFFFFFu << up) : 0xFFFFFFFFu;

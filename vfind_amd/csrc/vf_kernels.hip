@@ -508,7 +508,7 @@ __global__ __launch_bounds__(kBlock) void k_dp(const uint32_t *__restrict__ rows
 // All per-column work is full-rate VALU (and/or/xor/add/not/shift) plus one LDS read of Eq.
 // Detections are collected as one "miss" bit per column and turned into at most two clusters of end
 // columns; clusters further apart than m + kerr have disjoint windows.
-struct Clusters { int ncl, jmin1, jmax1, jmin2, jmax2; };
+struct Clusters { int ncl, jmin1, jmax1, jmin2, jmax2, dmin; };   // dmin: smallest D[m][j] over columns 1..4*floor(n/4)
 
 // one Myers column; sc tracks the last adapter row (bit 31) through the horizontal deltas.  Shifts by a
 // constant, and/or/xor/add and v_bitop3 on VGPRs are all full rate; carry-chain adds are not.
@@ -538,6 +538,9 @@ __device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int
     int sc = (int)dp.m - dp.kerr - 1;                  // unit edit distance minus (kerr + 1): negative <=> detected
     const int gap = (int)dp.m + dp.kerr;
     cl.ncl = 0; cl.jmin1 = 0; cl.jmax1 = 0; cl.jmin2 = 0; cl.jmax2 = 0;
+    // running minimum of sc over every column computed, and its value at the last 4-column boundary inside the
+    // lane's own read: columns past the read end are computed on zero padding and must not count
+    int smin = sc, smin_own = sc;
     const int nwords = (n + 15) >> 4;
     int nw_max = nwords;
 #pragma unroll
@@ -581,8 +584,9 @@ __device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int
                 for (int q = 0; q < 8; ++q) e[q] = eq_pair(q == 0 ? (word << 3) & 0x78u : (word >> (4 * q - 3)) & 0x78u);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    myers_column(e[q].x, Pv, Mv, sc); det = funnel(det, (uint32_t)sc, 31);
-                    myers_column(e[q].y, Pv, Mv, sc); det = funnel(det, (uint32_t)sc, 31);
+                    myers_column(e[q].x, Pv, Mv, sc); det = funnel(det, (uint32_t)sc, 31); smin = min(smin, sc);
+                    myers_column(e[q].y, Pv, Mv, sc); det = funnel(det, (uint32_t)sc, 31); smin = min(smin, sc);
+                    if (q & 1) smin_own = 16 * w + 2 * (q + 1) <= n ? smin : smin_own;
                 }
                 // bit 15-k <=> column 16w+k+1; only the lane's own columns count
                 const int kmax = min(16, n - 16 * w);
@@ -601,16 +605,18 @@ __device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int
             }
         }
     }
+    cl.dmin = smin_own + dp.kerr + 1;
 }
 
 constexpr int kMaxWindow = 64;   // columns the windowed DP holds in registers (5 dwords incl. phase)
-// Window classes: tasks of similar trip count share waves (a wave runs its longest window).
-//   0..2 one window by length, 3 two disjoint windows, 4 anything else -> full-width DP
-__device__ __forceinline__ int window_class(const Clusters &cl, int a1, int a2, int base) {
+constexpr int kBand = 8;         // diagonals the banded DP (k_dpb) computes
+constexpr int kBandBias = 4096;  // class-0 window word = first diagonal + kBandBias
+// Task classes: tasks of similar trip count share waves (a wave runs its longest window).
+//   0 banded (k_dpb), 1..2 one window by length, 3 two disjoint windows, 4 anything else -> full-width DP
+__device__ __forceinline__ int window_class(const Clusters &cl, int a1, int a2, int base, int kerr) {
     const int w1 = cl.jmax1 - a1, w2 = cl.jmax2 - a2;
     if (cl.ncl == 1) {
-        if (w1 <= base + 8) return 0;
-        if (w1 <= base + 20) return 1;
+        if (w1 <= min(base + max(8, 2 * kerr - 4), kMaxWindow)) return 1;      // the usual width of a task with two unit edits
         return w1 <= kMaxWindow ? 2 : 4;
     }
     if (cl.ncl == 2 && w1 <= kMaxWindow && w2 <= kMaxWindow) return 3;
@@ -644,14 +650,27 @@ __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ 
             if (valid && !any) (void)dp_commit(true, r, n, false, 0, dp, spans);
             const int base = (int)dp.m + dp.kerr;
             const int a1 = max(0, cl.jmin1 - base), a2 = max(0, cl.jmin2 - base);
-            const int cls = window_class(cl, a1, a2, base);
+            int cls = window_class(cl, a1, a2, base, dp.kerr);
+            // A task whose best own column has unit edit distance <= 1 has an optimum of at least match*m - c_max,
+            // so all its optimal alignments have at most kerr_lo unit edits (host: fill_dp).  Their end columns
+            // have D <= kerr_lo; D changes by at most one per column, so such a column lies kerr - kerr_lo columns
+            // inside the cluster of columns with D <= kerr on every side the read does not cut off.  The cells on
+            // those alignments lie on the diagonals j - i in [lo - m - kerr_lo, hi - m + kerr_lo]: class 0 when
+            // that band is at most kBand wide.
+            int av = 0;
+            if (dp.kerr_lo >= 0 && cl.dmin <= 1 && cl.ncl == 1) {
+                const int dl = dp.kerr - dp.kerr_lo;
+                const int lo = cl.jmin1 > 1 ? cl.jmin1 + dl : 1;
+                const int hi = cl.jmax1 < n ? cl.jmax1 - dl : n;
+                if (hi >= lo && hi - lo + 2 * dp.kerr_lo + 1 <= kBand) { cls = 0; av = lo - (int)dp.m - dp.kerr_lo; }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const bool mine = any && cls == q;
                 const uint32_t iw = wave_append(&s_c[q], mine);
                 if (mine) {
                     bl.listW[q][seg0 + iw] = r;
-                    bl.winW[q][seg0 + iw] = (uint32_t)a1 | ((uint32_t)cl.jmax1 << 16);
+                    bl.winW[q][seg0 + iw] = q == 0 ? (uint32_t)(av + kBandBias) : ((uint32_t)a1 | ((uint32_t)cl.jmax1 << 16));
                     if (q == 3) bl.winW2[seg0 + iw] = (uint32_t)a2 | ((uint32_t)cl.jmax2 << 16);
                 }
             }
@@ -760,6 +779,116 @@ __global__ __launch_bounds__(kBlock) void k_dpw(const uint32_t *__restrict__ row
         }
         int score, len;
         dp_window<M, TWO>(rows + (uint64_t)r * W, W, n, wa, wb, wa2, wb2, dp, L, score, len);
+        const bool pushS = dp_commit(valid, r, n, score >= dp.T, len, dp, spans);
+        if (dp.is_prefix) push_suffix(bl, seg, r, pushS);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_dpb: the same DP over a band of kBand diagonals (class 0 of the filter: every optimal alignment of the
+// task stays on diagonals j - i in [av, av + kBand)).  Relative column k = j - av runs from
+// 1 to M + kBand - 1 and holds the rows (k - kBand, k]: the code is fully unrolled over k, so the row a
+// register holds is static, a cell costs what it costs in dp_column and only M * kBand cells are computed
+// instead of M * (m + kerr + spread).  Everything outside the band reads as -inf (entering row, row above
+// the band) or as the true boundary value (row 0; column 0 when the band starts left of the read, where
+// av < 0 stands for an adapter overhanging the read start): a value that is never above the true one and
+// exact on every cell of an optimal alignment, which is all the result depends on.  A lane is active
+// from its first real column (j >= 1) to its last (j <= n): per-column exec masks, no divergent loops.
+// ------------------------------------------------------------------------------------------------
+template <int M>
+__device__ __forceinline__ void dp_banded(const uint32_t *__restrict__ row, int W, int n, int av, const DpParams &dp, const DpLds &L,
+                                          int &score, int &len) {
+    constexpr int KT = M + kBand - 1;
+    int32_t H[M], E[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {                       // column 0 of the read (only read where it is the true boundary)
+        H[i] = (int32_t)(((uint32_t)(-dp.mismatch * (i + 1)) << kScoreShift) | (uint32_t)(kLenBias - (i + 1)));
+        E[i] = kNegE;
+    }
+    const int k0 = av < 0 ? 1 - av : 1;
+    const int kend = min(KT, n - av);
+    // bases of relative columns 1..KT at bits [2(k-1), 2k) of Q: the row shifted by av bases (either way)
+    const int wb = av >> 4;                             // floor
+    const uint32_t ph = 2u * (uint32_t)(av & 15);
+    uint32_t x[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x[t] = (wb + t >= 0 && wb + t < W) ? row[wb + t] : 0u;
+    uint32_t Q[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) Q[t] = funnel(x[t + 1], x[t], ph);
+    const int32_t e_open = to_vgpr(dp.e_open_k), e_ext = to_vgpr(dp.e_ext_k), f_open = to_vgpr(dp.f_open_k), f_ext = to_vgpr(dp.f_ext_k);
+    int32_t best_s = -(1 << 24), best_v = 0;
+    bool done = false;
+    score = 0; len = 0;
+#pragma unroll
+    for (int k = 1; k <= KT; ++k) {
+        if (k >= k0 && k <= kend) {
+            const int r0 = k - kBand + 1 > 1 ? k - kBand + 1 : 1, r1 = k < M ? k : M;     // rows of this column, 1-based
+            const uint32_t b = (Q[(k - 1) >> 4] >> (2 * ((k - 1) & 15))) & 3u;
+            const int32_t *pc = L.prof + b * kProfStride;
+            int32_t pv[M + 3];
+#pragma unroll
+            for (int q = (r0 - 1) / 4; q <= (r1 - 1) / 4; ++q) {
+                const int4 v = reinterpret_cast<const int4 *>(pc)[q];
+                pv[4 * q] = v.x; pv[4 * q + 1] = v.y; pv[4 * q + 2] = v.z; pv[4 * q + 3] = v.w;
+            }
+            int32_t hup = r0 == 1 ? kV0 : kNegE, f1 = kNegF;
+            int32_t hdiag = r0 == 1 ? kV0 : H[r0 - 2];
+#pragma unroll
+            for (int r = r0; r <= r1; ++r) {
+                const int32_t hc = r == k ? kNegE : H[r - 1], ec = r == k ? kNegE : E[r - 1];   // row k enters the band here
+                const int32_t e = max(hc + e_open, ec + e_ext) & kClr;
+                const int32_t f = max(hup + f_open, f1 + f_ext) | (int32_t)(1u << kPrefShift);
+                const int32_t d = hdiag + pv[r - 1];
+                const int32_t h = max(max(d, f), e) & kClr;
+                hdiag = hc;
+                H[r - 1] = h;
+                E[r - 1] = e;
+                hup = h;
+                f1 = f;
+            }
+            if (r1 == M) dp_track(H[M - 1], best_s, best_v);
+            if (av + k == n) {                          // the read's last column: policy P3 over the rows of the band
+                int bscore = best_s + dp.mismatch * M;
+                int blen = (int)((uint32_t)best_v & kLenMask) + M - kLenBias;
+#pragma unroll
+                for (int r = r0; r <= (r1 < M - 1 ? r1 : M - 1); ++r) {
+                    const int si = (H[r - 1] >> kScoreShift) + dp.mismatch * r;
+                    if (si > bscore) { bscore = si; blen = (int)((uint32_t)H[r - 1] & kLenMask) + r - kLenBias; }
+                }
+                score = bscore; len = blen; done = true;
+            }
+        }
+    }
+    if (!done) {
+        score = best_s + dp.mismatch * M;
+        len = (int)((uint32_t)best_v & kLenMask) + M - kLenBias;
+    }
+}
+
+template <int M>
+__global__ __launch_bounds__(kBlock) void k_dpb(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
+                                                DpParams dp, short2 *__restrict__ spans, BatchLists bl) {
+    __shared__ FlatList fl;
+    __shared__ DpLds L;
+    dp_lds_fill(L, dp);
+    const uint32_t *list = bl.listW[0], *win = bl.winW[0];
+    flat_build(fl, bl.cntW[0], bl.grid);
+    const uint32_t total = fl.pre[kMaxGrid];
+    const uint32_t n_round = (total + WAVE - 1) / WAVE * WAVE;
+    for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < n_round; t += gridDim.x * kBlock) {
+        const bool valid = t < total;
+        uint32_t r = 0, seg = 0;
+        int n = 0, av = 0;
+        if (valid) {
+            seg = flat_segment(fl, t);
+            const uint64_t at = (uint64_t)seg * bl.seg + (t - fl.pre[seg]);
+            r = list[at];
+            n = lens[r];
+            av = (int)win[at] - kBandBias;
+        }
+        int score, len;
+        dp_banded<M>(rows + (uint64_t)r * W, W, n, av, dp, L, score, len);
         const bool pushS = dp_commit(valid, r, n, score >= dp.T, len, dp, spans);
         if (dp.is_prefix) push_suffix(bl, seg, r, pushS);
     }
@@ -1803,6 +1932,7 @@ static void launch_dp_m(hipStream_t s, int which, int g, const uint32_t *rows, c
                         short2 *spans, BatchLists bl, const uint32_t *list, const uint32_t *cnt, uint32_t count_stat,
                         uint64_t *counters) {
     if (which == 0) hipLaunchKernelGGL(k_dp<M>, dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, list, cnt, count_stat, counters);
+    else if (which == 1) hipLaunchKernelGGL(k_dpb<M>, dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl);
     else if (which - 1 < 3) hipLaunchKernelGGL((k_dpw<M, false>), dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, which - 1);
     else hipLaunchKernelGGL((k_dpw<M, true>), dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, which - 1);
 }
