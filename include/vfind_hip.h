@@ -161,6 +161,8 @@ int vf_table_merge(vf_ctx *ctx, const void *d_blob, uint64_t nbytes);
 
 int vf_stats_get(vf_ctx *ctx, vf_stats *out);
 int vf_stats_reset(vf_ctx *ctx);
+/* on: 0 off; 1 HIP events around every kernel of the path; 2 around the table kernel (k_finish) only -- each
+   bracket is two event packets on the stream, and a step has about twenty of them (measured 6 % of a step) */
 int vf_set_profiling(vf_ctx *ctx, int on);
 
 /* Host-side helpers shared by hosts that pack themselves. */

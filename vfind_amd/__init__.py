@@ -211,8 +211,9 @@ class Engine:
         return time.perf_counter() - t0
 
     # ---- stats ----------------------------------------------------------------------------------
-    def set_profiling(self, on: bool):
-        check(self._L.vf_set_profiling(self._ctx, int(bool(on))))
+    def set_profiling(self, on):
+        """0/False off, 1/True events around every kernel, 2 around the table kernel only"""
+        check(self._L.vf_set_profiling(self._ctx, int(on)))
 
     def stats(self) -> dict:
         s = VfStats()

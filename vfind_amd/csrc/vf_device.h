@@ -104,6 +104,7 @@ struct BatchLists {        // per in-flight batch; lists are segmented per workg
     uint32_t *winW2;                  // second window of class-3 (two-window) tasks
     uint32_t *listF;                  // filter output: tasks only the full-width DP can take
     uint32_t *cntP, *cntS, *cntW[4], *cntF;   // kMaxGrid entries each
+    uint32_t *tot;                    // [2][8]: tasks per class (0..3, 4 = full-width rest) of the prefix / suffix filter pass
     uint32_t grid, seg;               // from scan_geometry(n)
 };
 
@@ -112,10 +113,10 @@ hipError_t launch_scan(hipStream_t s, int W, const uint32_t *rows, const uint16_
                        const ScanParams &sp, short2 *spans, BatchLists bl);
 hipError_t launch_filter(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
                          short2 *spans, BatchLists bl, uint64_t *counters);
-hipError_t launch_dp_window(hipStream_t s, int cls, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
-                            short2 *spans, BatchLists bl);
+hipError_t launch_dp_classes(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
+                             short2 *spans, BatchLists bl, uint64_t *counters);
 hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
-                     short2 *spans, BatchLists bl, bool from_filter, uint64_t *counters);
+                     short2 *spans, BatchLists bl, uint64_t *counters);
 hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n,
                          const short2 *spans, bool skip_translation, Table t);
 hipError_t launch_generic(hipStream_t s, const uint8_t *bytes, const uint64_t *offs, uint64_t n,
@@ -127,6 +128,8 @@ hipError_t launch_line_index(hipStream_t s, const uint8_t *text, uint64_t n, uin
                              uint32_t *info);
 hipError_t launch_frame_pack(hipStream_t s, int W, const uint8_t *text, const uint32_t *line_end, uint32_t n_rec, uint32_t *rows,
                              uint16_t *lens, uint32_t *gen_start, uint32_t *gen_len, uint32_t *info, bool all_generic);
+struct ClearRegions { void *p[4]; uint64_t bytes[4]; };   // 16-byte aligned starts, sizes multiples of 4
+hipError_t launch_clear(hipStream_t s, const ClearRegions &cr);
 hipError_t launch_export(hipStream_t s, Table t, uint64_t *out_refs, uint64_t *out_counts, uint32_t *out_arena);
 hipError_t launch_rehash(hipStream_t s, Table from, Table to);
 hipError_t launch_merge(hipStream_t s, Table t, const uint64_t *refs, const uint64_t *counts,

@@ -104,7 +104,7 @@ struct Workspace {               // device scratch of one in-flight batch
         }
         if ((rc = winW2.ensure((size_t)g * seg))) return rc;
         if ((rc = listF.ensure((size_t)g * seg))) return rc;
-        return cnt.ensure(7 * kMaxGrid);
+        return cnt.ensure(7 * kMaxGrid + 16);
     }
     void release() {
         spans.release(); listP.release(); listS.release(); listF.release(); winW2.release(); cnt.release();
@@ -112,23 +112,12 @@ struct Workspace {               // device scratch of one in-flight batch
     }
 };
 
-// side streams of one in-order lane of work (a batch slot, or the resident path): concurrent DP consumers
+// one in-order lane of work (a batch slot, or the resident path).  It used to own a side stream for the rare DP
+// classes; all classes are one launch now (k_dpall), and every extra stream is one more candidate to share a
+// hardware queue with the table clear.
 struct Lane {
-    static constexpr int kSide = 1;
-    hipStream_t side[kSide] = {nullptr};
-    hipEvent_t fork = nullptr, join[kSide] = {nullptr};
-    int init() {
-        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return fail(VF_EDEVICE, "hipEventCreate failed");
-        for (int i = 0; i < kSide; ++i) {
-            if (hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess) return fail(VF_EDEVICE, "hipStreamCreate failed");
-            if (hipEventCreateWithFlags(&join[i], hipEventDisableTiming) != hipSuccess) return fail(VF_EDEVICE, "hipEventCreate failed");
-        }
-        return VF_OK;
-    }
-    void destroy() {
-        for (int i = 0; i < kSide; ++i) { if (side[i]) (void)hipStreamDestroy(side[i]); if (join[i]) (void)hipEventDestroy(join[i]); }
-        if (fork) (void)hipEventDestroy(fork);
-    }
+    int init() { return VF_OK; }
+    void destroy() {}
 };
 
 struct Slot;
@@ -203,7 +192,7 @@ struct vf_ctx {
     DevBuf<uint64_t> exp_refs, exp_counts;
     // stats / profiling
     std::atomic<uint64_t> n_reads{0}, n_generic{0};
-    bool profiling = false;
+    int profiling = 0;                  // 0 off, 1 every kernel bracket, 2 the table kernel (k_finish) only
     std::mutex ev_mu;
     std::vector<EventPair> pending_events;
     double ms[K_KINDS] = {0, 0, 0, 0, 0, 0};
@@ -301,11 +290,13 @@ static void fill_dp(DpParams &d, const std::string &ad, int64_t T, const vf_ctx 
 // create / destroy
 // ------------------------------------------------------------------------------------------------
 static int table_clear_locked(vf_ctx *c, bool all_counters = false) {
-    HIP_TRY(hipMemsetAsync(c->t_slots.p, 0, c->table_slots * 64, c->main_stream));
-    HIP_TRY(hipMemsetAsync(c->t_counts.p, 0, c->table_slots * kXcds * sizeof(uint64_t), c->main_stream));
-    HIP_TRY(hipMemsetAsync(c->t_chunks.p, 0, (size_t)kChunkRows * kMaxGrid * sizeof(unsigned long long), c->main_stream));
     // arena top, entry count and error bits belong to the table; the read statistics do not
-    HIP_TRY(hipMemsetAsync(c->t_counters.p, 0, (all_counters ? (size_t)C_NUM : (size_t)kTableCounters) * sizeof(uint64_t), c->main_stream));
+    ClearRegions cr;
+    cr.p[0] = c->t_slots.p;    cr.bytes[0] = c->table_slots * 64;
+    cr.p[1] = c->t_counts.p;   cr.bytes[1] = c->table_slots * kXcds * sizeof(uint64_t);
+    cr.p[2] = c->t_chunks.p;   cr.bytes[2] = (uint64_t)kChunkRows * kMaxGrid * sizeof(unsigned long long);
+    cr.p[3] = c->t_counters.p; cr.bytes[3] = (all_counters ? (uint64_t)C_NUM : (uint64_t)kTableCounters) * sizeof(uint64_t);
+    HIP_TRY(launch_clear(c->main_stream, cr));
     // batch streams order their next table access after this clear through the event (no host sync)
     HIP_TRY(hipEventRecord(c->clear_event, c->main_stream));
     return VF_OK;
@@ -461,7 +452,7 @@ static int resolve_events(vf_ctx *c) {
 }
 struct Timed {
     vf_ctx *c; hipStream_t s; int kind; hipEvent_t a = nullptr, b = nullptr; bool on;
-    Timed(vf_ctx *c_, hipStream_t s_, int k) : c(c_), s(s_), kind(k), on(c_->profiling) {
+    Timed(vf_ctx *c_, hipStream_t s_, int k) : c(c_), s(s_), kind(k), on(c_->profiling == 1 || (c_->profiling == 2 && k == K_FIN)) {
         if (on) {
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
             (void)hipEventRecord(a, s);
@@ -583,6 +574,7 @@ static int run_packed(vf_ctx *c, hipStream_t st, Lane &lane, uint32_t chunk_row,
     bl.listP = ws.listP.p; bl.listS = ws.listS.p; bl.listF = ws.listF.p;
     bl.cntP = ws.cnt.p; bl.cntS = ws.cnt.p + kMaxGrid; bl.cntF = ws.cnt.p + 2 * kMaxGrid;
     bl.winW2 = ws.winW2.p;
+    bl.tot = ws.cnt.p + 7 * kMaxGrid;
     for (int q = 0; q < 4; ++q) { bl.listW[q] = ws.listW[q].p; bl.winW[q] = ws.winW[q].p; bl.cntW[q] = ws.cnt.p + (3 + q) * kMaxGrid; }
     scan_geometry(n, &bl.grid, &bl.seg);
     // counting mode skips the suffix alignment of a read whose prefix failed (same table, less work);
@@ -596,28 +588,13 @@ static int run_packed(vf_ctx *c, hipStream_t st, Lane &lane, uint32_t chunk_row,
         if (role == 0 ? c->skip_pre : c->skip_suf) continue;
         const DpParams &dp = role == 0 ? dpP : dpS;
         if (c->filter_on) {
-            // The five consumers of the filter's lists (four window classes + the full-width rest) are
-            // independent.  The two shortest-window classes - where nearly all tasks are, which of the two
-            // depends on the adapter length - run back to back on the lane's stream; the long-window class, the
-            // two-window class and the full-width rest (a handful of tasks, but one wave's latency of a whole
-            // read) run beside them on the lane's side stream (one side stream per lane: the device exposes
-            // four hardware queues, more streams than that alias and serialise).
+            // One consumer launch for all five task classes of the filter (k_dpall splits its grid by the class totals
+            // the filter leaves behind): no side stream, no fork/join events.
             { Timed t(c, st, K_FILTER); HIP_TRY(launch_filter(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters)); }
-            HIP_TRY(hipEventRecord(lane.fork, st));
-            hipStream_t side = lane.side[0];
-            HIP_TRY(hipStreamWaitEvent(side, lane.fork, 0));
-            { Timed t(c, st, K_DPW); HIP_TRY(launch_dp_window(st, 0, W, d_rows, d_lens, dp, d_spans, bl)); }       // one kernel: the roofline line's unit
-            { Timed t(c, st, K_DPREST); HIP_TRY(launch_dp_window(st, 1, W, d_rows, d_lens, dp, d_spans, bl)); }
-            {
-                Timed t(c, side, K_DPREST);
-                HIP_TRY(launch_dp(side, W, d_rows, d_lens, dp, d_spans, bl, true, c->tab.counters));
-                for (int q = 2; q < 4; ++q) HIP_TRY(launch_dp_window(side, q, W, d_rows, d_lens, dp, d_spans, bl));
-            }
-            HIP_TRY(hipEventRecord(lane.join[0], side));
-            HIP_TRY(hipStreamWaitEvent(st, lane.join[0], 0));
+            { Timed t(c, st, K_DPW); HIP_TRY(launch_dp_classes(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters)); }
         } else {
             Timed t(c, st, K_DPREST);
-            HIP_TRY(launch_dp(st, W, d_rows, d_lens, dp, d_spans, bl, false, c->tab.counters));
+            HIP_TRY(launch_dp(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters));
         }
     }
     Table tab = c->tab;
@@ -1128,7 +1105,7 @@ extern "C" int vf_stats_reset(vf_ctx *c) {
 }
 extern "C" int vf_set_profiling(vf_ctx *c, int on) {
     if (!c) return fail(VF_EINVAL, "null context");
-    c->profiling = on != 0;
+    c->profiling = on == 2 ? 2 : (on != 0 ? 1 : 0);
     return VF_OK;
 }
 

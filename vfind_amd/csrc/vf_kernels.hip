@@ -203,6 +203,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ ro
                                                  BatchLists bl) {
     __shared__ uint32_t s_cnt[2];
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 16) bl.tot[threadIdx.x] = 0;      // per-class task totals of the two filter passes
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const uint64_t n_round = (n_reads + WAVE - 1) / WAVE * WAVE;
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ ro
 // v_and_or, v_alignbit, v_cndmask, v_cmp at HALF rate (scripts/ubench/valu_rate*.hip), so the cell is
 // built from full-rate ops except the three unavoidable maxima:
 //   E: add add max and | F: add add max or | diag: add (+LDS) | H: max3 and   = 14 issue units
-// Two columns are unrolled with ping-pong register sets so no cell value is ever copied.
+// Columns are updated in place (a cell is read before it is written), so no cell value is ever copied.
 //
 // Tie policy P through the 3-bit preference field: candidates enter each max with distinct
 // preferences (E: open 0 < extend 1;  F: open 2 < extend 3;  H: diag 4 > F 3 > E 0), the integer max
@@ -352,7 +353,7 @@ __device__ __forceinline__ void dp_result(const int32_t (&H)[M], int32_t best_s,
 // full-width DP: every column of the read, 16 bases a dword
 template <int M>
 __device__ __forceinline__ void dp_align(const uint32_t *__restrict__ row, int n, const DpParams &dp, const DpLds &L, int &score, int &len) {
-    int32_t HA[M], EA[M], HB[M], EB[M];
+    int32_t HA[M], EA[M];
     dp_init<M>(HA, EA, dp, true);
     int32_t best_s = INT32_MIN, best_v = 0, hl;
     const int nwords = (n + 15) >> 4;
@@ -361,19 +362,10 @@ __device__ __forceinline__ void dp_align(const uint32_t *__restrict__ row, int n
         uint32_t word = word_next;
         if (w + 1 < nwords) word_next = row[w + 1];
         const int kmax = min(16, n - 16 * w);
-        int k = 0;
-        for (; k + 2 <= kmax; k += 2) {
-            dp_column<M>(HA, EA, HB, EB, L.prof + (word & 3u) * kProfStride, dp, hl);
+        for (int k = 0; k < kmax; ++k) {                 // in place: a cell is read (hc, ec) before it is written
+            dp_column<M>(HA, EA, HA, EA, L.prof + (word & 3u) * kProfStride, dp, hl);
             dp_track(hl, best_s, best_v);
-            dp_column<M>(HB, EB, HA, EA, L.prof + ((word >> 2) & 3u) * kProfStride, dp, hl);
-            dp_track(hl, best_s, best_v);
-            word >>= 4;
-        }
-        if (k < kmax) {                      // odd tail (only in the last word)
-            dp_column<M>(HA, EA, HB, EB, L.prof + (word & 3u) * kProfStride, dp, hl);
-            dp_track(hl, best_s, best_v);
-#pragma unroll
-            for (int i = 0; i < M; ++i) { HA[i] = HB[i]; EA[i] = EB[i]; }
+            word >>= 2;
         }
     }
     if (nwords == 0) { score = INT32_MIN / 2; len = 0; return; }
@@ -461,17 +453,15 @@ __device__ __forceinline__ void push_suffix(const BatchLists &bl, uint32_t seg, 
 
 // Full-width DP over the tasks of the segmented list (list, cnt)
 template <int M>
-__global__ __launch_bounds__(kBlock) void k_dp(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
-                                               DpParams dp, short2 *__restrict__ spans, BatchLists bl,
-                                               const uint32_t *__restrict__ list, const uint32_t *__restrict__ cnt,
-                                               uint32_t count_stat, uint64_t *__restrict__ counters) {
-    __shared__ FlatList fl;
-    __shared__ DpLds L;
+__device__ __forceinline__ void dp_full_body(FlatList &fl, DpLds &L, const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
+                                             const DpParams &dp, short2 *__restrict__ spans, const BatchLists &bl,
+                                             const uint32_t *__restrict__ list, const uint32_t *__restrict__ cnt,
+                                             uint32_t count_stat, uint64_t *__restrict__ counters, uint32_t bid, uint32_t nb) {
     dp_lds_fill(L, dp);
     flat_build(fl, cnt, bl.grid);
     const uint32_t total = fl.pre[kMaxGrid];
     const uint32_t n_round = (total + WAVE - 1) / WAVE * WAVE;
-    for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < n_round; t += gridDim.x * kBlock) {
+    for (uint32_t t = bid * kBlock + threadIdx.x; t < n_round; t += nb * kBlock) {
         const bool valid = t < total;
         uint32_t r = 0, seg = 0;
         int n = 0;
@@ -485,8 +475,18 @@ __global__ __launch_bounds__(kBlock) void k_dp(const uint32_t *__restrict__ rows
         const bool pushS = dp_commit(valid, r, n, score >= dp.T, len, dp, spans);
         if (dp.is_prefix) push_suffix(bl, seg, r, pushS);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && count_stat && total)
+    if (bid == 0 && threadIdx.x == 0 && count_stat && total)
         atomicAdd((unsigned long long *)&counters[dp.is_prefix ? C_DP_PREFIX : C_DP_SUFFIX], (unsigned long long)total);
+}
+
+template <int M>
+__global__ __launch_bounds__(kBlock) void k_dp(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
+                                               DpParams dp, short2 *__restrict__ spans, BatchLists bl,
+                                               const uint32_t *__restrict__ list, const uint32_t *__restrict__ cnt,
+                                               uint32_t count_stat, uint64_t *__restrict__ counters) {
+    __shared__ FlatList fl;
+    __shared__ DpLds L;
+    dp_full_body<M>(fl, L, rows, lens, W, dp, spans, bl, list, cnt, count_stat, counters, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -681,6 +681,7 @@ __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ 
         __syncthreads();
         if (threadIdx.x < 4) bl.cntW[threadIdx.x][b] = s_c[threadIdx.x];
         if (threadIdx.x == 4) bl.cntF[b] = s_c[4];
+        if (threadIdx.x < 5 && s_c[threadIdx.x]) atomicAdd(&bl.tot[(dp.is_prefix ? 0u : 8u) + threadIdx.x], s_c[threadIdx.x]);
         stat += ntask;
         __syncthreads();
     }
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ 
 // the same DP as dp_align over read columns (a, b] only; column a is the boundary: the true first
 // column when a == 0, otherwise -inf (every cell left of the window is off all accepting paths)
 template <int M>
-__device__ __forceinline__ void dp_window_run(int32_t (&HA)[M], int32_t (&EA)[M], int32_t (&HB)[M], int32_t (&EB)[M],
+__device__ __forceinline__ void dp_window_run(int32_t (&HA)[M], int32_t (&EA)[M],
                                               const uint32_t *__restrict__ row, int W, int a, int b, const DpParams &dp,
                                               const DpLds &L, int32_t &best_s, int32_t &best_v) {
     dp_init<M>(HA, EA, dp, a == 0);
@@ -706,29 +707,21 @@ __device__ __forceinline__ void dp_window_run(int32_t (&HA)[M], int32_t (&EA)[M]
     q0 = funnel(q1, q0, ph); q1 = funnel(q2, q1, ph); q2 = funnel(q3, q2, ph); q3 = funnel(q4, q3, ph); q4 >>= ph;
     int32_t hl;
     const int wlen = b - a;
-#ifdef VF_DP_INPLACE
-    (void)HB; (void)EB;
-    for (int t = 0; t < wlen; ++t) {
-        dp_column<M>(HA, EA, HA, EA, L.prof + (q0 & 3u) * kProfStride, dp, hl);
-        dp_track(hl, best_s, best_v);
-        q0 = funnel(q1, q0, 2); q1 = funnel(q2, q1, 2); q2 = funnel(q3, q2, 2); q3 = funnel(q4, q3, 2); q4 >>= 2;
-    }
-#else
+    // in place (a cell is read before it is written): half the registers of a ping-pong pair of columns, which is
+    // what lets the DP waves of one batch lane sit next to the k_finish waves of the other
     int t = 0;
     for (; t + 2 <= wlen; t += 2) {
-        dp_column<M>(HA, EA, HB, EB, L.prof + (q0 & 3u) * kProfStride, dp, hl);
+        dp_column<M>(HA, EA, HA, EA, L.prof + (q0 & 3u) * kProfStride, dp, hl);
         dp_track(hl, best_s, best_v);
-        dp_column<M>(HB, EB, HA, EA, L.prof + ((q0 >> 2) & 3u) * kProfStride, dp, hl);
+        asm volatile("" : "+v"(q0) : "v"(HA[M / 2]));        // the second column's profile is fetched while the first one's lower half runs, not before it (registers)
+        dp_column<M>(HA, EA, HA, EA, L.prof + ((q0 >> 2) & 3u) * kProfStride, dp, hl);
         dp_track(hl, best_s, best_v);
         q0 = funnel(q1, q0, 4); q1 = funnel(q2, q1, 4); q2 = funnel(q3, q2, 4); q3 = funnel(q4, q3, 4); q4 >>= 4;
     }
     if (t < wlen) {
-        dp_column<M>(HA, EA, HB, EB, L.prof + (q0 & 3u) * kProfStride, dp, hl);
+        dp_column<M>(HA, EA, HA, EA, L.prof + (q0 & 3u) * kProfStride, dp, hl);
         dp_track(hl, best_s, best_v);
-#pragma unroll
-        for (int i = 0; i < M; ++i) { HA[i] = HB[i]; EA[i] = EB[i]; }
     }
-#endif
 }
 
 // one window, or two disjoint windows left to right (the cells between them are off all accepting
@@ -737,29 +730,27 @@ __device__ __forceinline__ void dp_window_run(int32_t (&HA)[M], int32_t (&EA)[M]
 template <int M, bool TWO>
 __device__ __forceinline__ void dp_window(const uint32_t *__restrict__ row, int W, int n, int a, int b, int a2, int b2,
                                           const DpParams &dp, const DpLds &L, int &score, int &len) {
-    int32_t HA[M], EA[M], HB[M], EB[M];
+    int32_t HA[M], EA[M];
     int32_t best_s = INT32_MIN, best_v = 0;
     if (b - a <= 0) { score = INT32_MIN / 2; len = 0; return; }
-    dp_window_run<M>(HA, EA, HB, EB, row, W, a, b, dp, L, best_s, best_v);
+    dp_window_run<M>(HA, EA, row, W, a, b, dp, L, best_s, best_v);
     int lastb = b;
     if (TWO) {
-        dp_window_run<M>(HA, EA, HB, EB, row, W, a2, b2, dp, L, best_s, best_v);
+        dp_window_run<M>(HA, EA, row, W, a2, b2, dp, L, best_s, best_v);
         lastb = b2;
     }
     dp_result<M>(HA, best_s, best_v, lastb == n, dp, score, len);
 }
 
 template <int M, bool TWO>
-__global__ __launch_bounds__(kBlock) void k_dpw(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
-                                                DpParams dp, short2 *__restrict__ spans, BatchLists bl, int cls) {
-    __shared__ FlatList fl;
-    __shared__ DpLds L;
+__device__ __forceinline__ void dpw_body(FlatList &fl, DpLds &L, const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
+                                         const DpParams &dp, short2 *__restrict__ spans, const BatchLists &bl, int cls, uint32_t bid, uint32_t nb) {
     dp_lds_fill(L, dp);
     const uint32_t *list = bl.listW[cls], *win = bl.winW[cls];
     flat_build(fl, bl.cntW[cls], bl.grid);
     const uint32_t total = fl.pre[kMaxGrid];
     const uint32_t n_round = (total + WAVE - 1) / WAVE * WAVE;
-    for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < n_round; t += gridDim.x * kBlock) {
+    for (uint32_t t = bid * kBlock + threadIdx.x; t < n_round; t += nb * kBlock) {
         const bool valid = t < total;
         uint32_t r = 0, seg = 0;
         int n = 0, wa = 0, wb = 0, wa2 = 0, wb2 = 0;
@@ -867,16 +858,14 @@ __device__ __forceinline__ void dp_banded(const uint32_t *__restrict__ row, int 
 }
 
 template <int M>
-__global__ __launch_bounds__(kBlock) void k_dpb(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
-                                                DpParams dp, short2 *__restrict__ spans, BatchLists bl) {
-    __shared__ FlatList fl;
-    __shared__ DpLds L;
+__device__ __forceinline__ void dpb_body(FlatList &fl, DpLds &L, const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
+                                         const DpParams &dp, short2 *__restrict__ spans, const BatchLists &bl, uint32_t bid, uint32_t nb) {
     dp_lds_fill(L, dp);
     const uint32_t *list = bl.listW[0], *win = bl.winW[0];
     flat_build(fl, bl.cntW[0], bl.grid);
     const uint32_t total = fl.pre[kMaxGrid];
     const uint32_t n_round = (total + WAVE - 1) / WAVE * WAVE;
-    for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < n_round; t += gridDim.x * kBlock) {
+    for (uint32_t t = bid * kBlock + threadIdx.x; t < n_round; t += nb * kBlock) {
         const bool valid = t < total;
         uint32_t r = 0, seg = 0;
         int n = 0, av = 0;
@@ -892,6 +881,66 @@ __global__ __launch_bounds__(kBlock) void k_dpb(const uint32_t *__restrict__ row
         const bool pushS = dp_commit(valid, r, n, score >= dp.T, len, dp, spans);
         if (dp.is_prefix) push_suffix(bl, seg, r, pushS);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_dpall: every task class of one filter pass in ONE launch.  The filter leaves the number of tasks per class
+// in bl.tot; every workgroup derives the same split of the grid from them -- blocks in proportion to tasks x
+// cells per task, at least one block for a class that has tasks, no more blocks than the class has waves --
+// and works on its class.  The rare classes (long windows, two windows, full-width rest) are a handful of tasks
+// each and cost one wave's latency (a whole read for the full-width rest): as launches of their own, on a side
+// stream, they took longer than the two big classes next to them, and the side streams shared hardware queues
+// with the table clear (a lane stalled behind another lane's k_finish: profiles/, checkpoint M).
+// ------------------------------------------------------------------------------------------------
+template <int M, int MODE>                               // MODE 0 every class, 1 the banded class only, 2 every class but the banded
+__global__ __launch_bounds__(kBlock) void k_dpall(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
+                                                  DpParams dp, short2 *__restrict__ spans, BatchLists bl, uint64_t *__restrict__ counters) {
+    __shared__ FlatList fl;
+    __shared__ DpLds L;
+    const uint32_t *tot = bl.tot + (dp.is_prefix ? 0u : 8u);
+    // relative cost of a task: banded M x kBand cells; one window ~ M x (m + kerr + 8); long / two windows ~ M x 64 x 1..2;
+    // full width M x read length
+    const uint32_t cost[5] = {2u, 8u, 16u, 24u, 64u};
+    uint32_t nbk[5], t5[5];
+    uint64_t wsum = 0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        t5[q] = ((MODE == 1 && q != 0) || (MODE == 2 && q == 0)) ? 0u : __builtin_amdgcn_readfirstlane(tot[q]);
+        wsum += (uint64_t)t5[q] * cost[q];
+    }
+    if (wsum == 0) return;
+    const uint32_t G = gridDim.x;
+    uint32_t used = 0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        uint32_t b = t5[q] ? (uint32_t)((uint64_t)G * t5[q] * cost[q] / wsum) : 0u;
+        const uint32_t cap = (t5[q] + kBlock - 1) / kBlock;              // one workgroup per 256 tasks at most
+        if (t5[q] && b < 1) b = 1;
+        if (b > cap) b = cap;
+        nbk[q] = b;
+        used += b;
+    }
+    // the floor of the shares plus the minimum of one can exceed the grid by at most four blocks: the largest class pays
+    if (used > G) {
+        int big = 0;
+#pragma unroll
+        for (int q = 1; q < 5; ++q) if (nbk[q] > nbk[big]) big = q;
+        nbk[big] -= used - G;
+    }
+    uint32_t b0 = 0;
+    const uint32_t b = blockIdx.x;
+    if (MODE != 2) {
+        if (b < b0 + nbk[0]) { dpb_body<M>(fl, L, rows, lens, W, dp, spans, bl, b - b0, nbk[0]); return; }
+        b0 += nbk[0];
+    }
+    if (MODE == 1) return;
+    if (b < b0 + nbk[1]) { dpw_body<M, false>(fl, L, rows, lens, W, dp, spans, bl, 1, b - b0, nbk[1]); return; }
+    b0 += nbk[1];
+    if (b < b0 + nbk[2]) { dpw_body<M, false>(fl, L, rows, lens, W, dp, spans, bl, 2, b - b0, nbk[2]); return; }
+    b0 += nbk[2];
+    if (b < b0 + nbk[3]) { dpw_body<M, true>(fl, L, rows, lens, W, dp, spans, bl, 3, b - b0, nbk[3]); return; }
+    b0 += nbk[3];
+    if (b < b0 + nbk[4]) dp_full_body<M>(fl, L, rows, lens, W, dp, spans, bl, bl.listF, bl.cntF, 0u, counters, b - b0, nbk[4]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1932,9 +1981,11 @@ static void launch_dp_m(hipStream_t s, int which, int g, const uint32_t *rows, c
                         short2 *spans, BatchLists bl, const uint32_t *list, const uint32_t *cnt, uint32_t count_stat,
                         uint64_t *counters) {
     if (which == 0) hipLaunchKernelGGL(k_dp<M>, dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, list, cnt, count_stat, counters);
-    else if (which == 1) hipLaunchKernelGGL(k_dpb<M>, dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl);
-    else if (which - 1 < 3) hipLaunchKernelGGL((k_dpw<M, false>), dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, which - 1);
-    else hipLaunchKernelGGL((k_dpw<M, true>), dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, which - 1);
+    else if (which == 1) hipLaunchKernelGGL((k_dpall<M, 0>), dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, counters);
+    else {
+        hipLaunchKernelGGL((k_dpall<M, 1>), dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, counters);
+        hipLaunchKernelGGL((k_dpall<M, 2>), dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, counters);
+    }
 }
 
 static hipError_t launch_dp_any(hipStream_t s, int which, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
@@ -1942,7 +1993,7 @@ static hipError_t launch_dp_any(hipStream_t s, int which, int W, const uint32_t 
                                 uint64_t *counters) {
     if (bl.grid == 0) return hipSuccess;
     static const uint32_t g_max = [] { const char *v = getenv("VFIND_DP_GRID"); const int x = v ? atoi(v) : 1024; return (uint32_t)(x >= 64 && x <= (int)kMaxGrid ? x : 1024); }();
-    const int g = (int)(bl.grid < g_max ? bl.grid : g_max);
+    const int g = which == 0 ? (int)(bl.grid < g_max ? bl.grid : g_max) : (int)g_max;
 #define VF_DP_CASE(M) case M: launch_dp_m<M>(s, which, g, rows, lens, W, dp, spans, bl, list, cnt, count_stat, counters); break;
     switch (dp.m) {
         VF_DP_CASE(1) VF_DP_CASE(2) VF_DP_CASE(3) VF_DP_CASE(4) VF_DP_CASE(5) VF_DP_CASE(6) VF_DP_CASE(7) VF_DP_CASE(8)
@@ -1955,18 +2006,20 @@ static hipError_t launch_dp_any(hipStream_t s, int which, int W, const uint32_t 
     return hipGetLastError();
 }
 
-// full-width DP over the role's own list (no filter) or over the filter's overflow list
+// full-width DP over the role's own list (scoring schemes that give the filter no usable bound)
 hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
-                     BatchLists bl, bool from_filter, uint64_t *counters) {
-    const uint32_t *list = from_filter ? bl.listF : (dp.is_prefix ? bl.listP : bl.listS);
-    const uint32_t *cnt = from_filter ? bl.cntF : (dp.is_prefix ? bl.cntP : bl.cntS);
-    return launch_dp_any(s, 0, W, rows, lens, dp, spans, bl, list, cnt, from_filter ? 0u : 1u, counters);
+                     BatchLists bl, uint64_t *counters) {
+    const uint32_t *list = dp.is_prefix ? bl.listP : bl.listS;
+    const uint32_t *cnt = dp.is_prefix ? bl.cntP : bl.cntS;
+    return launch_dp_any(s, 0, W, rows, lens, dp, spans, bl, list, cnt, 1u, counters);
 }
 
-// window class `cls` (0..3) of the filter's output
-hipError_t launch_dp_window(hipStream_t s, int cls, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
-                            short2 *spans, BatchLists bl) {
-    return launch_dp_any(s, 1 + cls, W, rows, lens, dp, spans, bl, nullptr, nullptr, 0u, nullptr);
+// every task class of the filter's output, one launch
+hipError_t launch_dp_classes(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
+                             BatchLists bl, uint64_t *counters) {
+    // VFIND_DP_SPLIT=1: the banded class as a launch of its own (fewer registers per wave), the other classes after it
+    static const int split = [] { const char *v = getenv("VFIND_DP_SPLIT"); return v ? atoi(v) : 0; }();
+    return launch_dp_any(s, split ? 2 : 1, W, rows, lens, dp, spans, bl, nullptr, nullptr, 0u, counters);
 }
 
 hipError_t launch_filter(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
@@ -2064,6 +2117,26 @@ hipError_t launch_frame_pack(hipStream_t s, int W, const uint8_t *text, const ui
     case 40: hipLaunchKernelGGL(k_frame_pack<40>, dim3(g), dim3(kBlock), 0, s, text, line_end, n_rec, rows, lens, gen_start, gen_len, info, all_generic ? 1 : 0); break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+// one launch zeroes the table's four regions with 16-byte stores from every CU (the runtime's fill kernel runs
+// 256 workgroups per memset and took 0.19 ms per clear for a 2^21-slot table: serial time between two k_finish)
+__global__ __launch_bounds__(kBlock) void k_clear(ClearRegions cr) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint4 *p = reinterpret_cast<uint4 *>(cr.p[q]);
+        const uint64_t n16 = cr.bytes[q] >> 4;
+        for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * kBlock) p[i] = z;
+        if (blockIdx.x == 0 && threadIdx.x < ((cr.bytes[q] & 15u) >> 2)) reinterpret_cast<uint32_t *>(p + n16)[threadIdx.x] = 0u;
+    }
+}
+
+hipError_t launch_clear(hipStream_t s, const ClearRegions &cr) {
+    for (int q = 0; q < 4; ++q)
+        if (((uintptr_t)cr.p[q] & 15u) || (cr.bytes[q] & 3u)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_clear, dim3(2048), dim3(kBlock), 0, s, cr);
     return hipGetLastError();
 }
 
