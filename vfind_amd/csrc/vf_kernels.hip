@@ -1329,10 +1329,38 @@ __device__ __forceinline__ void finish_key(uint32_t (&x)[W + 2], int start, int 
 // One-shot lookup of a key that is (most often) already in the table: hash, one slot line, compare.
 // Anything else - empty slot, another key in the slot, a key still being published, a LONG key - is a
 // miss here and goes to the workgroup's slow list, where table_find_or_insert runs with full waves.
+// the home slot's line for the one-shot lookup: only the 16-byte quarters the lane's own key reaches (w0 and two key
+// dwords, then four dwords each), and nothing for a lane without a key.  A slot whose w0 matches holds a key of the
+// same length, zero padded like the lane's, so the quarters left out compare equal by construction; a quarter is
+// one request at the L2, and the lookup is bound by requests (a 12-letter peptide needs two of the four).
+__device__ __forceinline__ void slot_load_key(const uint4 *p, uint32_t nd, bool can, uint4 &a, uint4 &b, uint4 &c, uint4 &d) {
+    u32x4 va = {0u, 0u, 0u, 0u}, vb = va, vc = va, vd = va;
+    // one asm block, predicated through exec: as separate statements the compiler copied a destination register
+    // between the load and the wait (it cannot know the result is still in flight)
+    const uint64_t m1 = __ballot(can), m2 = __ballot(can && nd > 2), m3 = __ballot(can && nd > 6), m4 = __ballot(can && nd > 10);
+    uint64_t save;
+    asm volatile("s_mov_b64 %4, exec\n\t"
+                 "s_mov_b64 exec, %6\n\t"
+                 "global_load_dwordx4 %0, %5, off sc1\n\t"
+                 "s_mov_b64 exec, %7\n\t"
+                 "global_load_dwordx4 %1, %5, off offset:16 sc1\n\t"
+                 "s_mov_b64 exec, %8\n\t"
+                 "global_load_dwordx4 %2, %5, off offset:32 sc1\n\t"
+                 "s_mov_b64 exec, %9\n\t"
+                 "global_load_dwordx4 %3, %5, off offset:48 sc1\n\t"
+                 "s_mov_b64 exec, %4\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "+v"(va), "+v"(vb), "+v"(vc), "+v"(vd), "=&s"(save)
+                 : "v"(p), "s"(m1), "s"(m2), "s"(m3), "s"(m4)
+                 : "memory");
+    a = make_uint4(va.x, va.y, va.z, va.w); b = make_uint4(vb.x, vb.y, vb.z, vb.w);
+    c = make_uint4(vc.x, vc.y, vc.z, vc.w); d = make_uint4(vd.x, vd.y, vd.z, vd.w);
+}
 struct FastProbe {
     uint32_t slot;
     uint64_t w0want;
     uint32_t kin[kInlineDwords];
+    uint32_t nd;
     bool can;
 };
 template <int ND>
@@ -1345,6 +1373,7 @@ __device__ __forceinline__ void fast_prepare(const Table &t, const uint32_t (&ke
     rk.each(nd, [&](uint32_t, uint32_t v) { hash_step(h, v); });
     hash_fin(h);
     p.can = act && nd <= (uint32_t)kInlineDwords;
+    p.nd = nd;
     p.w0want = (uint64_t)h.h2 | ((uint64_t)meta << 32) | kW0Ready;
     p.slot = h.h1 & t.slot_mask;
     rk.head(nd, p.kin);
@@ -1386,6 +1415,11 @@ __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ 
     __shared__ BlockTable bt;
     __shared__ uint32_t s_stat[3];
     __shared__ uint32_t s_slow[kBlock / WAVE][kSlowCap];
+    // the kernel waits on memory most of the time; what little it issues should not queue behind the DP waves of
+    // the other batch lane (uniform branch: s_setprio takes an immediate)
+    if (t.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (t.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (t.prio == 3) __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x < 64) lut[threadIdx.x] = c_codon_le[threadIdx.x];
     if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
     agg_init(agg);
@@ -1464,7 +1498,7 @@ __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ 
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         uint4 a, b, c, d;
-                        slot_load(t.slots + (uint64_t)fp[u].slot * 4, a, b, c, d);
+                        slot_load_key(t.slots + (uint64_t)fp[u].slot * 4, fp[u].nd, fp[u].can, a, b, c, d);
                         found[u] = fast_check(fp[u], a, b, c, d);
                     }
                 }
@@ -2048,6 +2082,8 @@ hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint1
     // four interleaved runs each): the 105-VGPR variant leaves more of the register file to the other batch lane
     static const bool u2 = [] { const char *v = getenv("VFIND_FINISH_U"); return v && atoi(v) == 2; }();
     const int g = grid_for(n, per_cu);
+    static const uint32_t prio = [] { const char *v = getenv("VFIND_FINISH_PRIO"); const int x = v ? atoi(v) : 0; return (uint32_t)(x >= 0 && x <= 3 ? x : 0); }();
+    t.prio = prio;
 #define VF_FINISH(WW, UU)                                                                                              \
     do {                                                                                                               \
         if (skip_translation) hipLaunchKernelGGL((k_finish<WW, UU, true>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t); \
