@@ -234,6 +234,7 @@ def main():
             raise SystemExit("MERGE CHECK FAILED: " + merge_error)
 
     if rank == 0:
+        is_cfg1 = (n, L, args.adapter_len, args.variants, args.sub_rate, args.indel_rate) == (10_000_000, 150, 20, 1_000_000, 0.005, 0.0005)
         ms_per_step = elapsed / args.steps * 1e3
         value = world * n * args.steps / elapsed / 1e6
         # per kernel: (summed event ms, launches, algorithmic bytes per launch).  A DP task reads its packed
@@ -272,7 +273,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{n} synthetic {L} bp reads per GPU per step, {args.adapter_len} bp adapters, default "
-                                   "alignment params (BASELINE.json configs[1]), reads resident in HBM",
+                                   "alignment params (" + ("BASELINE.json configs[1]" if is_cfg1 else "not configs[1]: see the other keys") + "), reads resident in HBM",
                        "reads_per_gpu": n, "read_len": L, "adapter_len": args.adapter_len, "variants": args.variants,
                        "sub_rate": args.sub_rate, "indel_rate": args.indel_rate, "parallelism": f"read-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

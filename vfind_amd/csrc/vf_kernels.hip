@@ -2075,9 +2075,10 @@ hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint1
     if (n >> 32) return hipErrorInvalidValue;         // read indices are 32-bit in the work lists
     hipError_t e = ensure_lut();
     if (e != hipSuccess) return e;
-    // two workgroups per CU measured best: the kernel is bound by the memory side (slot lines, count lines, CAS),
-    // more resident waves only add contention there and take registers from the batch lane running next to it
-    static const int per_cu = [] { const char *v = getenv("VFIND_FINISH_BLOCKS_PER_CU"); const int x = v ? atoi(v) : 2; return x >= 1 && x <= 8 ? x : 2; }();
+    // three workgroups per CU measured best next to a second batch lane (10.5 vs 10.3 at two and 10.1 G reads/s at four,
+    // interleaved runs): the kernel is bound by the memory side (slot lines, count lines, CAS), more resident waves add
+    // contention there and take registers from the DP waves of the other lane
+    static const int per_cu = [] { const char *v = getenv("VFIND_FINISH_BLOCKS_PER_CU"); const int x = v ? atoi(v) : 3; return x >= 1 && x <= 8 ? x : 3; }();
     // one read per lane and trip measured best once the kernel runs two workgroups per CU (7.44 vs 7.23 G reads/s over
     // four interleaved runs each): the 105-VGPR variant leaves more of the register file to the other batch lane
     static const bool u2 = [] { const char *v = getenv("VFIND_FINISH_U"); return v && atoi(v) == 2; }();
