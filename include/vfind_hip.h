@@ -74,9 +74,9 @@ typedef struct vf_stats {
     uint64_t table_entries;    /* distinct keys on the device                            */
     uint64_t arena_dwords;     /* total key dwords held by the table                     */
     /* device time per kernel, milliseconds, summed over launches (HIP events on the stream the kernel
-       is launched on; filled only while profiling is on).  dp_window = the shortest window class (one kernel
-       per adapter), dp_rest = every other DP launch: the second class on the same stream and the side
-       stream's group (long-window class, two-window class, full-width DP) */
+       is launched on; filled only while profiling is on).  dp_window = the DP launch that follows the filter (one
+       kernel per adapter, every task class), dp_rest = the whole-read DP of scoring schemes that give the filter
+       no bound */
     double ms_scan, ms_filter, ms_dp_window, ms_dp_rest, ms_finish, ms_generic;
     uint64_t launches_scan, launches_filter, launches_dp_window, launches_dp_rest, launches_finish, launches_generic;
     uint64_t insert_path;      /* counted reads whose one-shot table lookup missed (new, displaced or racing keys) */

@@ -95,7 +95,6 @@ struct Table {
     uint64_t *counters;
     uint32_t slot_mask;
     uint64_t arena_cap;               // dwords
-    uint32_t prio;                    // k_finish: wave priority (s_setprio) while it shares the CUs with another lane's DP waves
 };
 
 // ---- launchers (vf_kernels.hip) ---------------------------------------------------------------

@@ -7,8 +7,10 @@
 //              whole pattern at the survivors; appends reads that need an alignment to per-workgroup lists
 //   k_filter   exact pre-filter of those reads: Myers bit-vector edit distance of the adapter against
 //              every column -> the DP windows that can hold an accepted alignment
-//   k_dpw/k_dp parasail sg_stats_scan semi-global affine DP with the `length` statistic
-//              (lib.rs:155-160), tie policy P of SURVEY.md App. B.3, over the windows / the whole read
+//   k_dpall    parasail sg_stats_scan semi-global affine DP with the `length` statistic
+//              (lib.rs:155-160), tie policy P of SURVEY.md App. B.3, for every task class of the filter in
+//              one launch: over a band of eight diagonals (tasks with one unit edit), over the window(s),
+//              over the whole read; k_dp = the whole-read DP alone when no filter applies
 //   k_finish   seq[start..end] extraction (lib.rs:288-290), translate (lib.rs:16-44) and the
 //              HashMap<String,u64> reduce (lib.rs:292-306) as a device hash-count table: one-shot lookup,
 //              dense insert list, counts in per-XCD arrays
@@ -892,7 +894,7 @@ __device__ __forceinline__ void dpb_body(FlatList &fl, DpLds &L, const uint32_t 
 // stream, they took longer than the two big classes next to them, and the side streams shared hardware queues
 // with the table clear (a lane stalled behind another lane's k_finish: profiles/, checkpoint M).
 // ------------------------------------------------------------------------------------------------
-template <int M, int MODE>                               // MODE 0 every class, 1 the banded class only, 2 every class but the banded
+template <int M>
 __global__ __launch_bounds__(kBlock) void k_dpall(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
                                                   DpParams dp, short2 *__restrict__ spans, BatchLists bl, uint64_t *__restrict__ counters) {
     __shared__ FlatList fl;
@@ -904,10 +906,7 @@ __global__ __launch_bounds__(kBlock) void k_dpall(const uint32_t *__restrict__ r
     uint32_t nbk[5], t5[5];
     uint64_t wsum = 0;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-        t5[q] = ((MODE == 1 && q != 0) || (MODE == 2 && q == 0)) ? 0u : __builtin_amdgcn_readfirstlane(tot[q]);
-        wsum += (uint64_t)t5[q] * cost[q];
-    }
+    for (int q = 0; q < 5; ++q) { t5[q] = __builtin_amdgcn_readfirstlane(tot[q]); wsum += (uint64_t)t5[q] * cost[q]; }
     if (wsum == 0) return;
     const uint32_t G = gridDim.x;
     uint32_t used = 0;
@@ -929,11 +928,8 @@ __global__ __launch_bounds__(kBlock) void k_dpall(const uint32_t *__restrict__ r
     }
     uint32_t b0 = 0;
     const uint32_t b = blockIdx.x;
-    if (MODE != 2) {
-        if (b < b0 + nbk[0]) { dpb_body<M>(fl, L, rows, lens, W, dp, spans, bl, b - b0, nbk[0]); return; }
-        b0 += nbk[0];
-    }
-    if (MODE == 1) return;
+    if (b < b0 + nbk[0]) { dpb_body<M>(fl, L, rows, lens, W, dp, spans, bl, b - b0, nbk[0]); return; }
+    b0 += nbk[0];
     if (b < b0 + nbk[1]) { dpw_body<M, false>(fl, L, rows, lens, W, dp, spans, bl, 1, b - b0, nbk[1]); return; }
     b0 += nbk[1];
     if (b < b0 + nbk[2]) { dpw_body<M, false>(fl, L, rows, lens, W, dp, spans, bl, 2, b - b0, nbk[2]); return; }
@@ -1415,11 +1411,6 @@ __global__ __launch_bounds__(kBlock) void k_finish(const uint32_t *__restrict__ 
     __shared__ BlockTable bt;
     __shared__ uint32_t s_stat[3];
     __shared__ uint32_t s_slow[kBlock / WAVE][kSlowCap];
-    // the kernel waits on memory most of the time; what little it issues should not queue behind the DP waves of
-    // the other batch lane (uniform branch: s_setprio takes an immediate)
-    if (t.prio == 1) __builtin_amdgcn_s_setprio(1);
-    else if (t.prio == 2) __builtin_amdgcn_s_setprio(2);
-    else if (t.prio == 3) __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x < 64) lut[threadIdx.x] = c_codon_le[threadIdx.x];
     if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
     agg_init(agg);
@@ -2015,11 +2006,7 @@ static void launch_dp_m(hipStream_t s, int which, int g, const uint32_t *rows, c
                         short2 *spans, BatchLists bl, const uint32_t *list, const uint32_t *cnt, uint32_t count_stat,
                         uint64_t *counters) {
     if (which == 0) hipLaunchKernelGGL(k_dp<M>, dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, list, cnt, count_stat, counters);
-    else if (which == 1) hipLaunchKernelGGL((k_dpall<M, 0>), dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, counters);
-    else {
-        hipLaunchKernelGGL((k_dpall<M, 1>), dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, counters);
-        hipLaunchKernelGGL((k_dpall<M, 2>), dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, counters);
-    }
+    else hipLaunchKernelGGL(k_dpall<M>, dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, counters);
 }
 
 static hipError_t launch_dp_any(hipStream_t s, int which, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
@@ -2051,9 +2038,8 @@ hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t 
 // every task class of the filter's output, one launch
 hipError_t launch_dp_classes(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
                              BatchLists bl, uint64_t *counters) {
-    // VFIND_DP_SPLIT=1: the banded class as a launch of its own (fewer registers per wave), the other classes after it
-    static const int split = [] { const char *v = getenv("VFIND_DP_SPLIT"); return v ? atoi(v) : 0; }();
-    return launch_dp_any(s, split ? 2 : 1, W, rows, lens, dp, spans, bl, nullptr, nullptr, 0u, counters);
+    // (the banded class as a launch of its own, 77 instead of 113 registers per wave, measured the same: 9.48 vs 9.43 G reads/s)
+    return launch_dp_any(s, 1, W, rows, lens, dp, spans, bl, nullptr, nullptr, 0u, counters);
 }
 
 hipError_t launch_filter(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
@@ -2083,8 +2069,6 @@ hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint1
     // four interleaved runs each): the 105-VGPR variant leaves more of the register file to the other batch lane
     static const bool u2 = [] { const char *v = getenv("VFIND_FINISH_U"); return v && atoi(v) == 2; }();
     const int g = grid_for(n, per_cu);
-    static const uint32_t prio = [] { const char *v = getenv("VFIND_FINISH_PRIO"); const int x = v ? atoi(v) : 0; return (uint32_t)(x >= 0 && x <= 3 ? x : 0); }();
-    t.prio = prio;
 #define VF_FINISH(WW, UU)                                                                                              \
     do {                                                                                                               \
         if (skip_translation) hipLaunchKernelGGL((k_finish<WW, UU, true>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t); \
