@@ -1964,7 +1964,11 @@ static int grid_for(uint64_t n, int per_cu) {
 }
 
 void scan_geometry(uint64_t n, uint32_t *grid, uint32_t *seg) {
-    const uint32_t g = (uint32_t)grid_for(n, 8);
+    // workgroups per CU of k_scan (and list segments, hence workgroups of k_filter): both kernels are persistent, and at
+    // eight per CU they hold every wave slot while the other batch lane's k_finish and the table clear want in;
+    // five measured best (10.8 against 10.5 G reads/s at eight, 10.7 at four, 10.4 at three, interleaved runs)
+    static const int per_cu = [] { const char *v = getenv("VFIND_SCAN_BLOCKS_PER_CU"); const int x = v ? atoi(v) : 5; return x >= 1 && x <= 8 ? x : 5; }();
+    const uint32_t g = (uint32_t)grid_for(n, per_cu);
     const uint64_t per_block = (n + (uint64_t)g * kBlock - 1) / ((uint64_t)g * kBlock) * kBlock;
     *grid = g;
     *seg = (uint32_t)per_block;
