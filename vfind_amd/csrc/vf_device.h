@@ -100,7 +100,7 @@ struct Table {
 // ---- launchers (vf_kernels.hip) ---------------------------------------------------------------
 struct BatchLists {        // per in-flight batch; lists are segmented per workgroup of k_scan
     uint32_t *listP, *listS;          // DP tasks per adapter (grid*seg entries each)
-    uint32_t *listW[4], *winW[4];     // filter output: windowed tasks by class (+ window a | b<<16)
+    uint32_t *listW[4], *winW[4];     // filter output by class: 0 banded (+ first diagonal + kBandBias), 1..3 windowed (+ window a | b<<16)
     uint32_t *winW2;                  // second window of class-3 (two-window) tasks
     uint32_t *listF;                  // filter output: tasks only the full-width DP can take
     uint32_t *cntP, *cntS, *cntW[4], *cntF;   // kMaxGrid entries each
