@@ -1,4 +1,4 @@
-"""CPU check of the argument behind the filter's class 0 and k_dpb's banded DP: the Python
+"""CPU check of the argument behind the filter's class 0 and the banded DP (dp_banded in k_dpall): the Python
 restatement of the kernel's control flow (tests/tools/band_model.py) must agree with the full-matrix DP of
 oracle/pyref.py (reference call: src/lib.rs:155-160) on random class-0 tasks -- and stop agreeing when the band is
 put in the wrong place, so the check is known to bite."""

@@ -251,7 +251,7 @@ def test_filter_and_window_edge_cases():
 
 
 def test_banded_class_single_edit_tasks():
-    """Tasks whose best end column has unit edit distance 1 take the banded DP (k_dpb, class 0 of the filter):
+    """Tasks whose best end column has unit edit distance 1 take the banded DP (dp_banded in k_dpall, class 0 of the filter):
     one substitution, one inserted or one deleted base at every adapter position, with the adapter at the read
     start (band left of column 0), at the read end (last-column cells, every read length mod 4), overhanging
     either end, and next to a second, worse copy; several scoring schemes and adapter lengths"""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""CPU model of the filter's class-0 decision and of k_dpb's banded DP (vf_kernels.hip), checked against the
+"""CPU model of the filter's class-0 decision and of the banded DP (dp_banded, vf_kernels.hip), checked against the
 full-matrix DP of oracle/pyref.py on random tasks.  No GPU: it restates the kernel's control flow (relative
 columns, rows per column, what a cell reads outside the band) in Python, so the argument of DESIGN.md 4.3
 (tightened edit bound, shrunk cluster, band of diagonals) is tested on its own.
@@ -67,7 +67,7 @@ def clusters(det_cols, gap):
 
 
 def banded(q, r, av, match, mismatch, gopen, gext):
-    """k_dpb restated: cells are (score, length); returns (score, length)"""
+    """dp_banded restated: cells are (score, length); returns (score, length)"""
     m, n = len(q), len(r)
     KT = m + KBAND - 1
     H = [(0, 0)] * m           # column 0 of the read

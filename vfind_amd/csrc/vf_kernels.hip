@@ -611,10 +611,10 @@ __device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int
 }
 
 constexpr int kMaxWindow = 64;   // columns the windowed DP holds in registers (5 dwords incl. phase)
-constexpr int kBand = 8;         // diagonals the banded DP (k_dpb) computes
+constexpr int kBand = 8;         // diagonals the banded DP (dp_banded) computes
 constexpr int kBandBias = 4096;  // class-0 window word = first diagonal + kBandBias
 // Task classes: tasks of similar trip count share waves (a wave runs its longest window).
-//   0 banded (k_dpb), 1..2 one window by length, 3 two disjoint windows, 4 anything else -> full-width DP
+//   0 banded (dp_banded), 1..2 one window by length, 3 two disjoint windows, 4 anything else -> full-width DP
 __device__ __forceinline__ int window_class(const Clusters &cl, int a1, int a2, int base, int kerr) {
     const int w1 = cl.jmax1 - a1, w2 = cl.jmax2 - a2;
     if (cl.ncl == 1) {
@@ -778,7 +778,7 @@ __device__ __forceinline__ void dpw_body(FlatList &fl, DpLds &L, const uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_dpb: the same DP over a band of kBand diagonals (class 0 of the filter: every optimal alignment of the
+// dp_banded: the same DP over a band of kBand diagonals (class 0 of the filter: every optimal alignment of the
 // task stays on diagonals j - i in [av, av + kBand)).  Relative column k = j - av runs from
 // 1 to M + kBand - 1 and holds the rows (k - kBand, k]: the code is fully unrolled over k, so the row a
 // register holds is static, a cell costs what it costs in dp_column and only M * kBand cells are computed
