@@ -105,6 +105,8 @@ def main():
     parity = None
     cpu = None
     oracle_full, oracle_full_n = None, 0
+    if world > 1:
+        args.no_cpu_baseline = True       # the CPU baseline is timed at N=1 only (the other ranks would wait for it)
     if rank == 0 and not (args.no_parity and args.no_cpu_baseline):
         from oracle import oracle          # the checker / CPU baseline; never part of the timed GPU path
         cores = min(os.cpu_count() or 1, 16)          # a 1-GPU box gives this job a 16-core share
