@@ -915,16 +915,22 @@ __global__ __launch_bounds__(kBlock) void k_dpall(const uint32_t *__restrict__ r
         uint32_t b = t5[q] ? (uint32_t)((uint64_t)G * t5[q] * cost[q] / wsum) : 0u;
         const uint32_t cap = (t5[q] + kBlock - 1) / kBlock;              // one workgroup per 256 tasks at most
         if (t5[q] && b < 1) b = 1;
+        if (q > 0 && cap <= 2 * b + 8) b = cap;                            // a small class runs as one trip: its latency is the launch's tail
         if (b > cap) b = cap;
         nbk[q] = b;
         used += b;
     }
-    // the floor of the shares plus the minimum of one can exceed the grid by at most four blocks: the largest class pays
-    if (used > G) {
-        int big = 0;
+    // the minimum of one block and the single-trip raise can exceed the grid: the largest classes pay (a class keeps one block)
 #pragma unroll
-        for (int q = 1; q < 5; ++q) if (nbk[q] > nbk[big]) big = q;
-        nbk[big] -= used - G;
+    for (int it = 0; it < 5; ++it) {
+        if (used > G) {
+            int big = 0;
+#pragma unroll
+            for (int q = 1; q < 5; ++q) if (nbk[q] > nbk[big]) big = q;
+            const uint32_t cut = min(used - G, nbk[big] - 1u);
+            nbk[big] -= cut;
+            used -= cut;
+        }
     }
     uint32_t b0 = 0;
     const uint32_t b = blockIdx.x;
