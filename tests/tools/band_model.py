@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from oracle import pyref  # noqa: E402  (test infrastructure)
 
 NEG = -(1 << 28)
-KBAND = 8
+KBAND = 10
 
 
 def max_unit_errors(T, m, match, mismatch, gopen, gext):

@@ -882,6 +882,15 @@ extern "C" int vf_process_device_packed(vf_ctx *c, const void *d_rows, uint32_t 
     HIP_TRY(hipEventRecord(L.done, L.stream));
     L.in_flight = true;
     c->n_reads += n;
+    // diagnosis: tasks per filter class of this batch (synchronises the lane; never set in a measurement)
+    static const bool dbg_classes = [] { const char *v = getenv("VFIND_DEBUG_CLASSES"); return v && atoi(v) != 0; }();
+    if (dbg_classes) {
+        uint32_t tot[16];
+        HIP_TRY(hipStreamSynchronize(L.stream));
+        HIP_TRY(hipMemcpy(tot, L.ws.cnt.p + 7 * kMaxGrid, sizeof(tot), hipMemcpyDeviceToHost));
+        fprintf(stderr, "vfind classes (banded, window, long window, two windows, full width): prefix %u %u %u %u %u  suffix %u %u %u %u %u\n",
+                tot[0], tot[1], tot[2], tot[3], tot[4], tot[8], tot[9], tot[10], tot[11], tot[12]);
+    }
     return VF_OK;
 }
 

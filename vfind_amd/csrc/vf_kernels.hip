@@ -9,7 +9,7 @@
 //              every column -> the DP windows that can hold an accepted alignment
 //   k_dpall    parasail sg_stats_scan semi-global affine DP with the `length` statistic
 //              (lib.rs:155-160), tie policy P of SURVEY.md App. B.3, for every task class of the filter in
-//              one launch: over a band of eight diagonals (tasks with one unit edit), over the window(s),
+//              one launch: over a band of ten diagonals (tasks with one unit edit), over the window(s),
 //              over the whole read; k_dp = the whole-read DP alone when no filter applies
 //   k_finish   seq[start..end] extraction (lib.rs:288-290), translate (lib.rs:16-44) and the
 //              HashMap<String,u64> reduce (lib.rs:292-306) as a device hash-count table: one-shot lookup,
@@ -611,7 +611,7 @@ __device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int
 }
 
 constexpr int kMaxWindow = 64;   // columns the windowed DP holds in registers (5 dwords incl. phase)
-constexpr int kBand = 8;         // diagonals the banded DP (dp_banded) computes
+constexpr int kBand = 10;        // diagonals the banded DP (dp_banded) computes
 constexpr int kBandBias = 4096;  // class-0 window word = first diagonal + kBandBias
 // Task classes: tasks of similar trip count share waves (a wave runs its longest window).
 //   0 banded (dp_banded), 1..2 one window by length, 3 two disjoint windows, 4 anything else -> full-width DP
