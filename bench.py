@@ -47,19 +47,55 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--table-slots", type=int, default=0, help="count-table slots (0 = 2x the variant library, power of two)")
+    ap.add_argument("--lib", default=None, help=argparse.SUPPRESS)      # diagnosis: another build of the library (make ablation)
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rank plumbing only (no device work): what the CPU test of --gpus N runs")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the same
+        # torch.distributed.run line the driver uses) as a CHILD process, before anything here has touched the GPU,
+        # and leave with its exit code.
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or run without a launcher)")
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
+    if args.dry_run:
+        # the N>1 plumbing without a device: ranks rendezvous, barrier, reduce a clock the way the timed region does
+        if world > 1:
+            dist.init_process_group("gloo" if args.backend != "nccl" or not torch.cuda.is_available() else "nccl")
+            dist.barrier()
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "max_over_ranks": float(t.item()),
+                              "scaling": "weak"}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     import vfind_amd
-    from vfind_amd import synth
+    from benchlib import synth
+    if args.lib:
+        from vfind_amd import _lib as _vl
+        _vl.SO_PATH = os.path.abspath(args.lib)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -306,7 +342,9 @@ def main():
         print(json.dumps(out), flush=True)
     if merge_error == "table merge did not finish in time":
         sys.stdout.flush()
-        os._exit(0)                                       # the stuck collective would block close() as well
+        sys.stderr.write("bench.py: the table merge did not finish in time (stuck collective)\n")
+        sys.stderr.flush()
+        os._exit(3)                                       # the stuck collective would block close() as well; never rc 0
     eng.close()
     if world > 1:
         dist.destroy_process_group()

@@ -1,12 +1,26 @@
-"""ctypes front-end of the seeded synthetic read generator (include/vfind_synth.h).
-Bench / test tooling: reads are a pure function of (config, read index)."""
+"""ctypes front-end of the seeded synthetic read generator (benchlib/vfind_synth.h, libvfind_synth.so).
+Bench / test tooling, not part of the product: reads are a pure function of (config, read index)."""
 from __future__ import annotations
 
 import ctypes as C
+import os
+import subprocess
 
 import numpy as np
 
-from . import _lib
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libvfind_synth.so")
+_L = None
+
+
+def build() -> str:
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+def row_dwords_for(max_len: int) -> int:
+    """row width of the packed layout (include/vfind_hip.h: vf_row_dwords_for)"""
+    return 10 if max_len <= 160 else 20 if max_len <= 320 else 40 if max_len <= 640 else 0
 
 
 class _Cfg(C.Structure):
@@ -17,7 +31,13 @@ class _Cfg(C.Structure):
 
 
 def _bind():
-    L = _lib.lib()
+    global _L
+    if _L is None:
+        src = os.path.join(_HERE, "vf_synth.cpp")
+        if not os.path.exists(_SO) or (os.path.exists(src) and os.path.getmtime(_SO) < os.path.getmtime(src)):
+            build()
+        _L = C.CDLL(_SO)
+    L = _L
     if not getattr(L, "_synth_bound", False):
         L.vf_synth_adapters.restype = C.c_int
         L.vf_synth_adapters.argtypes = [C.c_uint64, C.c_uint32, C.c_char_p, C.c_char_p]
@@ -52,7 +72,7 @@ class Generator:
         if self._L.vf_synth_create(C.byref(cfg), C.byref(self._g)):
             raise ValueError("bad synth config")
         self.read_len = read_len
-        self.row_dwords = int(self._L.vf_row_dwords_for(read_len))
+        self.row_dwords = row_dwords_for(read_len)
 
     def close(self):
         if self._g:

@@ -1,6 +1,6 @@
-// vf_synth.cpp -- seeded synthetic read generator (bench / test tooling; see include/vfind_synth.h)
-#include "../../include/vfind_synth.h"
-#include "../../include/vfind_hip.h"
+// vf_synth.cpp -- seeded synthetic read generator (bench / test tooling; see vfind_synth.h).
+// Built into benchlib/libvfind_synth.so: not part of the product library, not part of the drop-in boundary.
+#include "vfind_synth.h"
 
 #include <algorithm>
 #include <cmath>
@@ -10,6 +10,18 @@
 #include <vector>
 
 namespace {
+enum { VF_OK = 0, VF_EINVAL = 1 };
+// 2-bit pack of an ACGT-only read (A0 C1 G2 T3, base k at bits [2k, 2k+1] of the row, zero padded); 1 = other byte met
+int pack_row(const uint8_t *seq, uint32_t n, uint32_t *row, uint32_t W) {
+    for (uint32_t w = 0; w < W; ++w) row[w] = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint8_t c = seq[k];
+        if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return 1;
+        const uint32_t x = (c >> 1) & 3u;
+        row[k >> 4] |= (x ^ (x >> 1)) << (2u * (k & 15u));
+    }
+    return 0;
+}
 struct Rng {
     uint64_t s;
     explicit Rng(uint64_t seed) : s(seed) {}
@@ -137,7 +149,7 @@ extern "C" int vf_synth_generate(const vf_synth *g, uint64_t first, uint64_t n, 
             for (uint64_t i = lo; i < hi; ++i) {
                 one_read(*g, first + i, buf, var);
                 if (ascii) memcpy(ascii + i * L, buf.data(), L);
-                if (rows && vf_pack_read((const uint8_t *)buf.data(), L, rows + i * W, W)) rc[t] = VF_EINVAL;
+                if (rows && pack_row((const uint8_t *)buf.data(), L, rows + i * W, W)) rc[t] = VF_EINVAL;
                 if (lens) lens[i] = (uint16_t)L;
             }
         });

@@ -1,7 +1,7 @@
 /*
  * vfind_synth.h -- seeded synthetic read generator used by bench.py and the parity tests
- * (SURVEY.md 8d).  Bench/test tooling exported from libvfind_hip.so; not part of the drop-in
- * boundary.  Every read is a pure function of (cfg, read index): read i is produced from the
+ * (SURVEY.md 8d).  Bench/test tooling in benchlib/libvfind_synth.so; not part of the product
+ * library or of the drop-in boundary.  Every read is a pure function of (cfg, read index): read i is produced from the
  * stream splitmix64(seed ^ i), so any read is reproducible on any host, rank or thread count.
  *
  *   read = flank5 | prefix' | variant | suffix' | filler, cut / padded with uniform ACGT to L

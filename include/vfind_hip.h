@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 1
+#define VF_ABI_VERSION 2
 
 enum {
     VF_OK = 0,
@@ -80,6 +80,7 @@ typedef struct vf_stats {
     double ms_scan, ms_filter, ms_dp_window, ms_dp_rest, ms_finish, ms_generic;
     uint64_t launches_scan, launches_filter, launches_dp_window, launches_dp_rest, launches_finish, launches_generic;
     uint64_t insert_path;      /* counted reads whose one-shot table lookup missed (new, displaced or racing keys) */
+    uint64_t arena_top;        /* dwords of the long-key arena handed out so far (keys longer than 56 bytes live there) */
 } vf_stats;
 
 const char *vf_last_error(void);

@@ -2,7 +2,7 @@ import sys, time
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import vfind_amd
-from vfind_amd import synth as vsynth
+from benchlib import synth as vsynth
 ads = vsynth.adapters(0x5EED0002, 20)
 gen = vsynth.Generator(0x5EED0002, ads, n_variants=100000)
 n = 2_000_000

@@ -4,7 +4,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import vfind_amd
-from vfind_amd import synth
+from benchlib import synth
 n = 10_000_000
 ads = synth.adapters(0x5EED0002, 20)
 gen = synth.Generator(0x5EED0002, ads)

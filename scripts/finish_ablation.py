@@ -3,7 +3,7 @@ import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
 import vfind_amd
-from vfind_amd import synth
+from benchlib import synth
 n = 10_000_000
 ads = synth.adapters(0x5EED0002, 20)
 gen = synth.Generator(0x5EED0002, ads)

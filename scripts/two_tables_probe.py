@@ -6,7 +6,7 @@ lanes = sys.argv[1] if len(sys.argv) > 1 else "1"
 os.environ["VFIND_RES_LANES"] = lanes
 import numpy as np, torch
 import vfind_amd
-from vfind_amd import synth
+from benchlib import synth
 n, L, seed = 10_000_000, 150, 0x5EED0002
 ads = synth.adapters(seed, 20)
 gen = synth.Generator(seed, ads, read_len=L, n_variants=1_000_000, sub_rate=0.005, indel_rate=0.0005)

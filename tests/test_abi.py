@@ -28,7 +28,7 @@ def test_header_symbols_all_exported():
     for name in sorted(declared):
         assert hasattr(so, name), f"{name} declared in include/vfind_hip.h but not exported"
     assert {s[0] for s in L.SYMBOLS} == declared
-    assert L.lib().vf_abi_version() == 1
+    assert L.lib().vf_abi_version() == L.ABI_VERSION == int(re.search(r"#define VF_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_pack_read_layout():

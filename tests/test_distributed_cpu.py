@@ -73,3 +73,19 @@ def test_shard_range_partitions(n, world):
     assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     sizes = [hi - lo for lo, hi in spans]
     assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks (before touching any GPU) and report
+    n_gpus == 2; a mismatch between --gpus and an existing WORLD_SIZE is refused"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--dry-run",
+                          "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["dry_run"] is True and j["max_over_ranks"] == 2.0
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=120,
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), cwd=ROOT)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)

@@ -101,6 +101,35 @@ def test_reader_false_start_that_inflates_for_long_does_not_starve(harness, tmp_
     # of the single-worker run shows it abandoned with abort=1 -- either way the output above is exact)
 
 
+def test_reader_required_task_is_always_started(harness, tmp_path, monkeypatch):
+    """Regression for the round-1 sequencer stall (gpurun_out/hang.log: head_pos == required, no task for it, every
+    worker asleep).  A worker drops the reader's lock while it scans for the next member magic; a request for the task
+    the sequencer is blocked on that arrives during that scan used to be lost (the worker went to sleep on its old view),
+    and with all workers in that state nothing ever started the needed task.  The worker now re-evaluates after every
+    re-lock (`retry` in inflate_worker).  Shape that provokes it: members larger than the 4 MiB task grid (so the
+    speculation frontier lags the head and every hand-over needs a request), a small speculation cap (speculative tasks
+    park early and the sequencer runs into unstarted members), several worker counts.  One run, bounded by a timeout."""
+    monkeypatch.setenv("VFIND_FASTQ_SPEC_CAP", str(256 << 10))
+    rng_reads = synth.make_reads(8, 150000, AD20, L=150)
+    # random quality strings keep the members above the 4 MiB grid after compression
+    import numpy as np
+    rng = np.random.default_rng(8)
+    n_members = 3
+    per = len(rng_reads) // n_members
+    members = []
+    for k in range(n_members):
+        part = rng_reads[k * per:(k + 1) * per]
+        quals = rng.integers(33, 74, (len(part), 150), dtype=np.uint8)
+        body = b"".join(b"@r%d\n" % (k * per + i) + r + b"\n+\n" + quals[i, :len(r)].tobytes() + b"\n" for i, r in enumerate(part))
+        members.append(gzip.compress(body, 1))
+    p = str(tmp_path / "big_members.gz")
+    open(p, "wb").write(b"".join(members))
+    assert min(len(m) for m in members) > (4 << 20)
+    want = _expect(rng_reads[:n_members * per])
+    for nt in (2, 3, 8):
+        assert _run(harness, p, nt, timeout=180, env={"VFIND_INFLATE_PARALLEL": "0"}) == want, nt
+
+
 def test_reader_errors(harness, tmp_path):
     good = synth.fastq_text(synth.make_reads(8, 5000, AD20, L=80))
     cases = {

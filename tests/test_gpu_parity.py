@@ -295,7 +295,7 @@ def test_banded_class_single_edit_tasks():
 def test_baseline_config_shapes_small_scale(name, kw):
     """BASELINE.json configs[1], [3], [4] at 40 k reads through the bench's own generator: spans and the
     (sequence,count) table equal the oracle; full sizes are covered by bench.py's parity gate"""
-    from vfind_amd import synth as vsynth
+    from benchlib import synth as vsynth
     ads = vsynth.adapters(kw["seed"], kw["m"])
     gen = vsynth.Generator(kw["seed"], ads, read_len=kw["read_len"], n_variants=5000, sub_rate=kw["sub_rate"], indel_rate=kw["indel_rate"])
     data, offs = gen.ascii(0, 40000, 8)
@@ -498,7 +498,8 @@ def test_capacity_error_is_loud():
     still gives the oracle's answer; a resident batch larger than the table cannot be saved and fails loudly,
     (the key arena for long keys grows with the streaming path as well)"""
     import torch
-    from vfind_amd import Engine, VfindError, synth as vsynth
+    from vfind_amd import Engine, VfindError
+    from benchlib import synth as vsynth
     reads = synth.make_reads(95, 4000, AD20, L=150, n_variants=2000)
     with Engine(AD20, skip_translation=True, table_slots=64, batch_reads=512) as e:
         e.submit(reads)
@@ -527,7 +528,8 @@ def test_counts_large_batch_hot_and_flat_keys(n_variants, zipf):
     """a million reads through the resident path: a few hundred hot keys (LDS aggregation, per-XCD count
     arrays summed at export) and a flat library (nearly every read a new or rare key: insert path)"""
     import torch
-    from vfind_amd import Engine, synth as vsynth
+    from vfind_amd import Engine
+    from benchlib import synth as vsynth
     gen = vsynth.Generator(0xC0FFEE + n_variants, AD20, n_variants=n_variants, zipf_s=zipf)
     n = 1_000_000
     rows, lens = gen.packed(0, n, 8)
@@ -574,12 +576,149 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     import sys
     from tests.conftest import ROOT
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--reads", "400000", "--variants", "30000", "--backend", "gloo", "--same-device", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    j = json.loads(line)
-    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
-    assert j["merge_ms"] is not None and j["parity_gate"] is True
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+            "--reads", "400000", "--variants", "30000", "--backend", "gloo", "--same-device", "--no-cpu-baseline"]
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    # the way the driver starts N > 1 (torch.distributed.run around bench.py), and bench.py --gpus 2 on its own, which
+    # must start the two ranks itself
+    for cmd in (launcher + tail, [sys.executable] + tail):
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        j = json.loads(line)
+        assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+        assert j["merge_ms"] is not None and j["parity_gate"] is True and j["merge_error"] is None
+
+
+def test_merge_grows_the_receiving_table():
+    """rank 0 of N merges its peers' tables into a table that was sized for its own keys: four exported tables of
+    disjoint keys go into a 1024-slot context (vf_table_merge reserves room from the blob header, as a submit does);
+    a blob whose header promises more than it holds is refused"""
+    import torch
+    from vfind_amd import Engine
+    rng = np.random.default_rng(123)
+    parts = []
+    for k in range(4):                                   # disjoint variant libraries: different seeds, 3000 variants each
+        parts.append(synth.make_reads(400 + k, 9000, AD20, L=150, n_variants=3000))
+    with Engine(AD20, table_slots=1 << 10, arena_bytes=1 << 22) as dst:
+        dst.submit(parts[0][:500])                       # a few keys of its own: the table stays at 1024 slots
+        bufs = []
+        for k in range(4):
+            with Engine(AD20, table_slots=1 << 14, arena_bytes=1 << 22) as src:
+                src.submit(parts[k])
+                n = src.export_size()
+                buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+                assert src.export_to(buf.data_ptr(), n + 64) == n
+                bufs.append((buf, n))
+        for buf, n in bufs:
+            dst.merge_from(buf.data_ptr(), n)
+        got = dst.finish_dict()
+        assert dst.stats()["table_entries"] > 1 << 10
+        # a header that claims more entries than the blob holds (u64 arithmetic must not wrap)
+        bad = bufs[0][0].clone()
+        bad[:8] = torch.tensor(list((1 << 61).to_bytes(8, "little")), dtype=torch.uint8)
+        with pytest.raises(ValueError, match="truncated"):
+            dst.merge_from(bad.data_ptr(), bufs[0][1])
+    want = oracle.count(parts[0][:500] + [r for p in parts for r in p], AD20)
+    assert got == want and len(got) > 4000
+    # long keys (arena) through the same path
+    long_a = synth.make_reads(410, 1500, AD20, L=600, n_variants=1500)
+    long_b = synth.make_reads(411, 1500, AD20, L=600, n_variants=1500)
+    with Engine(AD20, skip_translation=True, table_slots=1 << 8, arena_bytes=1 << 14) as dst, \
+         Engine(AD20, skip_translation=True, table_slots=1 << 12, arena_bytes=1 << 22) as src:
+        dst.submit(long_a[:50])
+        src.submit(long_b)
+        n = src.export_size()
+        buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+        src.export_to(buf.data_ptr(), n + 64)
+        dst.merge_from(buf.data_ptr(), n)
+        assert dst.finish_dict() == oracle.count(long_a[:50] + long_b, AD20, skip_translation=True)
+
+
+def test_table_growth_keeps_long_keys_in_place():
+    """keys longer than 56 bytes live in the arena; growing the table re-inserts every entry and must not copy those
+    keys again (each growth used to double the arena's fill): 600-base regions, table started at 64 slots"""
+    from vfind_amd import Engine
+    reads = synth.make_reads(420, 6000, AD20, L=600, n_variants=6000)
+    want = oracle.count(reads, AD20, skip_translation=True)
+    with Engine(AD20, skip_translation=True, table_slots=64, arena_bytes=1 << 16, batch_reads=500) as e:
+        e.submit(reads)
+        got = e.finish_dict()
+        st = e.stats()
+    assert got == want and max(len(k) for k in got) > 224
+    assert st["table_entries"] >= 2000                  # grew from 64 slots several times
+    # arena handed out = the keys' own dwords plus chunk slack (one partial 1024-dword chunk per workgroup and stream),
+    # not a multiple of them
+    assert st["arena_top"] <= st["arena_dwords"] + 4 * 2048 * 1024, st
+    assert st["arena_top"] < 2 * st["arena_dwords"] + (1 << 20), st
+
+
+def test_two_files_into_one_context(tmp_path):
+    """BASELINE configs[2] shape: R1 and R2 as two gzip FASTQ files counted into ONE table (run_fastq twice on one
+    context) equals the oracle on the concatenation"""
+    import vfind_amd
+    r1 = synth.make_reads(430, 40000, AD20, L=150, sub=0.01, indel=0.002, n_variants=600)
+    r2 = synth.make_reads(431, 30000, AD20, L=150, sub=0.01, indel=0.002, n_variants=600, dirty=0.01)
+    p1, p2 = str(tmp_path / "r1.fq.gz"), str(tmp_path / "r2.fq.gz")
+    synth.write_fastq_gz(p1, r1, members=4)
+    synth.write_fastq_gz(p2, r2, members=1)
+    with vfind_amd.Engine(AD20, n_threads=4, table_slots=1 << 14) as e:
+        e.run_fastq(p1)
+        e.run_fastq(p2)
+        got = e.finish_dict()
+        assert e.stats()["reads"] == len(r1) + len(r2)
+    assert got == oracle.count(r1 + r2, AD20)
+
+
+def test_counting_path_spans_follow_the_oracle():
+    """the counting path skips the suffix alignment of a read whose prefix failed (a read without a start contributes
+    nothing, lib.rs:288); its per-read coordinates must equal the oracle's wherever the oracle finds a start, and hold
+    no start wherever the oracle finds none"""
+    import torch
+    from vfind_amd import Engine
+    from benchlib import synth as vsynth
+    for seed, sub, indel in ((0x5EED0002, 0.005, 0.0005), (0x5EED0004, 0.15, 0.0), (77, 0.04, 0.02)):
+        ads = vsynth.adapters(seed, 20)
+        gen = vsynth.Generator(seed, ads, n_variants=20000, sub_rate=sub, indel_rate=indel)
+        n = 200_000
+        rows, lens = gen.packed(0, n, 8)
+        data, offs = gen.ascii(0, n, 8)
+        d_rows = torch.from_numpy(rows).cuda()
+        d_lens = torch.from_numpy(lens.view("int16")).cuda()
+        d_spans = torch.empty((n, 2), dtype=torch.int16, device="cuda")
+        with Engine(ads, table_slots=1 << 17) as e:
+            e.process_device(d_rows.data_ptr(), rows.shape[1], d_lens.data_ptr(), n, d_spans.data_ptr())
+            got = e.finish_dict()
+        sp = d_spans.cpu().numpy().astype(np.int64)
+        ost, oen = oracle.spans((data, offs), ads, n_threads=8)
+        has = ost >= 0
+        assert (sp[has, 0] == ost[has]).all() and (sp[has, 1] == np.maximum(oen[has], -1)).all()
+        assert (sp[~has, 0] < 0).all()
+        assert has.sum() > n // 10 and (~has).sum() > 1000
+        assert got == oracle.count((data, offs), ads, n_threads=8)
+
+
+@pytest.mark.parametrize("name,kw,n", [
+    ("cfg4", dict(seed=0x5EED0004, read_len=150, m=20, sub_rate=0.15, indel_rate=0.0, n_variants=1_000_000), 1_000_000),
+    ("cfg5", dict(seed=0x5EED0005, read_len=300, m=30, sub_rate=0.005, indel_rate=0.0005, n_variants=10_000_000), 1_000_000)])
+def test_baseline_config_shapes_million_reads(name, kw, n):
+    """BASELINE.json configs[3] and [4] shapes (15 % adapter substitutions: an alignment on nearly every read; 300 bp reads,
+    30 bp adapters, 10^7-variant library) at 10^6 reads through the resident path: the whole table equals the oracle's"""
+    import torch
+    from vfind_amd import Engine
+    from benchlib import synth as vsynth
+    ads = vsynth.adapters(kw["seed"], kw["m"])
+    gen = vsynth.Generator(kw["seed"], ads, read_len=kw["read_len"], n_variants=kw["n_variants"], sub_rate=kw["sub_rate"], indel_rate=kw["indel_rate"])
+    rows, lens = gen.packed(0, n, 8)
+    data, offs = gen.ascii(0, n, 8)
+    want = oracle.count((data, offs), ads, n_threads=16)
+    d_rows = torch.from_numpy(rows).cuda()
+    d_lens = torch.from_numpy(lens.view("int16")).cuda()
+    with Engine(ads, table_slots=1 << 21) as e:
+        e.process_device(d_rows.data_ptr(), rows.shape[1], d_lens.data_ptr(), n)
+        got = e.finish_dict()
+        st = e.stats()
+    assert got == want and len(got) > 10000
+    assert st["dp_prefix"] > (500_000 if name == "cfg4" else 50_000)

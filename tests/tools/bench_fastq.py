@@ -4,7 +4,7 @@ import argparse, gzip, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import vfind_amd
-from vfind_amd import synth
+from benchlib import synth
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--reads", type=int, default=4_000_000)

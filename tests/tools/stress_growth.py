@@ -2,7 +2,7 @@
 import os, sys, time, gzip
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import vfind_amd
-from vfind_amd import synth
+from benchlib import synth
 from oracle import oracle
 ads = synth.adapters(0x5EED0003, 20)
 gen = synth.Generator(0x5EED0003, ads)

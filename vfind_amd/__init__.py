@@ -148,7 +148,10 @@ class Engine:
     def finish(self):
         """the (sequence, count) frame of lib.rs:312-319: polars.DataFrame if polars is importable, else
         a pyarrow.Table; the buffers come straight from the library through the Arrow C Data Interface"""
-        import pyarrow as pa
+        try:
+            import pyarrow as pa
+        except ImportError:                    # polars alone is enough (the reference needs nothing else): plain arrays
+            return _to_frame(*self.finish_arrays())
 
         res = C.c_void_p()
         check(self._L.vf_finish(self._ctx, C.byref(res)))
@@ -156,7 +159,17 @@ class Engine:
             arr = (C.c_uint64 * 10)()          # struct ArrowArray
             sch = (C.c_uint64 * 9)()           # struct ArrowSchema
             check(self._L.vf_result_export_arrow(res, C.addressof(arr), C.addressof(sch)))
-            batch = pa.RecordBatch._import_from_c(C.addressof(arr), C.addressof(sch))
+            try:
+                batch = pa.RecordBatch._import_from_c(C.addressof(arr), C.addressof(sch))
+            except BaseException:
+                # the exported structures own the buffers now: release them as a consumer would (C Data Interface:
+                # `release` is member 8 of ArrowArray and member 7 of ArrowSchema, null once released)
+                rel = C.CFUNCTYPE(None, C.c_void_p)
+                if arr[8]:
+                    rel(arr[8])(C.addressof(arr))
+                if sch[7]:
+                    rel(sch[7])(C.addressof(sch))
+                raise
         finally:
             self._L.vf_result_free(res)
         try:

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libvfind_hip.so")
 
 VF_OK, VF_EINVAL, VF_EIO, VF_EFORMAT, VF_EDEVICE, VF_ECAPACITY, VF_ENOMEM = range(7)
+ABI_VERSION = 2          # VF_ABI_VERSION of include/vfind_hip.h
 
 
 class VfParams(C.Structure):
@@ -34,7 +35,7 @@ class VfStats(C.Structure):
         "reads", "reads_generic", "dp_prefix", "dp_suffix", "accepted", "counted", "table_entries", "arena_dwords")] + [
         (n, C.c_double) for n in ("ms_scan", "ms_filter", "ms_dp_window", "ms_dp_rest", "ms_finish", "ms_generic")] + [
         (n, C.c_uint64) for n in ("launches_scan", "launches_filter", "launches_dp_window", "launches_dp_rest", "launches_finish", "launches_generic",
-                                  "insert_path")]
+                                  "insert_path", "arena_top")]
 
 
 # every symbol include/vfind_hip.h declares: (name, restype, argtypes)
@@ -97,7 +98,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.vf_abi_version() != 1:
+        if L.vf_abi_version() != ABI_VERSION:
             raise ImportError("libvfind_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -180,6 +180,7 @@ static void run_task(Reader &R, const std::shared_ptr<Task> &t) {
     dec->begin(R.file + t->start, file_end);
     Piece piece;
     piece.data = R.pieces.get();
+    bool oom = piece.data == nullptr;
     size_t fill = 0;
     auto flush_piece = [&](bool final_piece) -> bool {      // returns false when aborted
         const size_t nl_count = fill ? count_newlines(piece.data, fill) : 0;
@@ -194,7 +195,10 @@ static void run_task(Reader &R, const std::shared_ptr<Task> &t) {
             fill = 0;
             R.cv.notify_all();
         }
-        if (!final_piece && !piece.data) { lk.unlock(); piece.data = R.pieces.get(); lk.lock(); }
+        if (!final_piece && !piece.data) {
+            lk.unlock(); piece.data = R.pieces.get(); lk.lock();
+            if (!piece.data) { oom = true; return false; }       // neither page-locked nor ordinary memory left
+        }
         if (final_piece) return true;
         // a task nobody needs yet may only run so far ahead; and it gives way when the sequencer is
         // blocked on a task no worker is decoding (a false start can inflate garbage for a long time,
@@ -204,10 +208,10 @@ static void run_task(Reader &R, const std::shared_ptr<Task> &t) {
         if (t->start != R.head_pos && starving()) t->abort = true;
         return !(t->abort || R.stop);
     };
-    bool ok = true;
-    std::string err;
+    bool ok = !oom;
+    std::string err = oom ? "out of memory: no buffer for inflated text" : "";
     uint64_t end = 0;
-    if (R.big_members) {
+    if (R.big_members && ok) {
         // one long deflate stream: every member is decoded by all threads (vf_pinflate.cpp)
         R.pieces.put(piece.data);
         piece = Piece();
@@ -247,15 +251,15 @@ static void run_task(Reader &R, const std::shared_ptr<Task> &t) {
         R.cv.notify_all();
         return;
     }
-    for (;;) {
-        if (kPiece - fill < 4096 && !flush_piece(false)) { ok = false; err = "aborted"; break; }
+    while (ok) {
+        if (kPiece - fill < 4096 && !flush_piece(false)) { ok = false; err = oom ? "out of memory: no buffer for inflated text" : "aborted"; break; }
         size_t got = 0;
         const vf::GzipMemberDecoder::Status st = dec->run(piece.data + fill, kPiece - fill, &got);
         fill += got;
         t->in_pos.store((uint64_t)(dec->in_pos() - R.file), std::memory_order_relaxed);
         if (st == vf::GzipMemberDecoder::kError) { ok = false; err = dec->error(); break; }
         if (st == vf::GzipMemberDecoder::kPieceFull) {
-            if (!flush_piece(false)) { ok = false; err = "aborted"; break; }
+            if (!flush_piece(false)) { ok = false; err = oom ? "out of memory: no buffer for inflated text" : "aborted"; break; }
             continue;
         }
         const uint64_t e = (uint64_t)(dec->in_pos() - R.file);      // absolute offset just past this member
@@ -286,6 +290,7 @@ static void run_task_zlib(Reader &R, const std::shared_ptr<Task> &t) {
     const uint64_t stop_at = next_grid(t->start);
     Piece piece;
     piece.data = R.pieces.get();
+    bool oom = piece.data == nullptr;
     size_t fill = 0;
     auto flush_piece = [&](bool final_piece) -> bool {      // returns false when aborted
         const size_t nl_count = fill ? count_newlines(piece.data, fill) : 0;
@@ -300,7 +305,10 @@ static void run_task_zlib(Reader &R, const std::shared_ptr<Task> &t) {
             fill = 0;
             R.cv.notify_all();
         }
-        if (!final_piece && !piece.data) { lk.unlock(); piece.data = R.pieces.get(); lk.lock(); }
+        if (!final_piece && !piece.data) {
+            lk.unlock(); piece.data = R.pieces.get(); lk.lock();
+            if (!piece.data) { oom = true; return false; }       // neither page-locked nor ordinary memory left
+        }
         if (final_piece) return true;
         // a task nobody needs yet may only run so far ahead; and it gives way when the sequencer is
         // blocked on a task no worker is decoding (a false start can inflate garbage for a long time,
@@ -310,10 +318,10 @@ static void run_task_zlib(Reader &R, const std::shared_ptr<Task> &t) {
         if (t->start != R.head_pos && starving()) t->abort = true;
         return !(t->abort || R.stop);
     };
-    bool ok = true;
-    std::string err;
+    bool ok = !oom;
+    std::string err = oom ? "out of memory: no buffer for inflated text" : "";
     uint64_t end = 0;
-    for (;;) {
+    while (ok) {
         if (z.avail_in == 0) {
             if (pos >= R.size) { ok = false; err = "gzip error: truncated stream"; break; }
             const uint64_t take = std::min<uint64_t>(R.size - pos, 1u << 30);
@@ -329,7 +337,7 @@ static void run_task_zlib(Reader &R, const std::shared_ptr<Task> &t) {
         if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) {
             ok = false; err = std::string("gzip error: ") + (z.msg ? z.msg : "corrupt stream"); break;
         }
-        if (fill == kPiece) { if (!flush_piece(false)) { ok = false; err = "aborted"; break; } }
+        if (fill == kPiece) { if (!flush_piece(false)) { ok = false; err = oom ? "out of memory: no buffer for inflated text" : "aborted"; break; } }
         if (rc == Z_STREAM_END) {
             const uint64_t e = pos - z.avail_in;            // absolute offset just past this member
             if (e >= R.size) { end = R.size; break; }
@@ -528,9 +536,10 @@ extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
                 // the chunk's byte ranges -> one contiguous buffer (this copy used to sit on the sequencer thread)
                 uint8_t *text = chunk_pool.get();
                 size_t at = 0;
-                for (auto &sg : ch->segs) { memcpy(text + at, sg.p, sg.n); at += sg.n; }
+                if (text) for (auto &sg : ch->segs) { memcpy(text + at, sg.p, sg.n); at += sg.n; }
                 ch->segs.clear();                            // pieces return to their pool
-                rc = frame_records(text, at, refs, err);
+                rc = text ? frame_records(text, at, refs, err) : VF_ENOMEM;
+                if (!text) err = "out of memory: no buffer for a text chunk";
                 if (!rc) {
                     if (g_dbg) fprintf(stderr, "[fastq] packer submits %zu reads at %.3f\n", refs.size(), now_s());
                     rc = vf_internal_submit(c, text, refs.data(), refs.size());

@@ -112,14 +112,6 @@ struct Workspace {               // device scratch of one in-flight batch
     }
 };
 
-// one in-order lane of work (a batch slot, or the resident path).  It used to own a side stream for the rare DP
-// classes; all classes are one launch now (k_dpall), and every extra stream is one more candidate to share a
-// hardware queue with the table clear.
-struct Lane {
-    int init() { return VF_OK; }
-    void destroy() {}
-};
-
 struct Slot;
 struct ResLane {                 // one of the in-order lanes vf_process_device_packed alternates between
     PinBuf<uint64_t> h_entries;  // table entry count as of this lane's latest finished batch
@@ -127,12 +119,10 @@ struct ResLane {                 // one of the in-order lanes vf_process_device_
     hipEvent_t done = nullptr;
     bool in_flight = false;
     uint32_t chunk_row = 0;
-    Lane lane;
     Workspace ws;
 };
 
 struct Slot {
-    Lane lane;
     PinBuf<uint64_t> h_entries;  // table entry count as of this slot's latest finished batch
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
@@ -184,7 +174,6 @@ struct vf_ctx {
     std::mutex mu;
     std::condition_variable cv;
     hipStream_t main_stream = nullptr;
-    Lane main_lane;
     hipEvent_t clear_event = nullptr;   // recorded on main_stream after each table clear
     static constexpr int kMaxResLanes = 4;
     ResLane res[kMaxResLanes];   // vf_process_device_packed: batch k+1's scan/DP overlaps batch k's finish
@@ -306,7 +295,9 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     if (!p || !out) return fail(VF_EINVAL, "null argument");
     *out = nullptr;
     if ((p->prefix_len && !p->prefix) || (p->suffix_len && !p->suffix)) return fail(VF_EINVAL, "null adapter");
-    std::unique_ptr<vf_ctx> c(new vf_ctx);
+    // every early return below destroys what has been created so far (streams, events, device buffers)
+    struct CtxDeleter { void operator()(vf_ctx *p) const { vf_ctx_destroy(p); } };
+    std::unique_ptr<vf_ctx, CtxDeleter> c(new vf_ctx);
     // prefix threshold is validated first (lib.rs:239), then suffix (lib.rs:249)
     int rc;
     if ((rc = preflight(p->accept_prefix_alignment, &c->skip_pre))) return rc;
@@ -322,6 +313,12 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     c->queue_len = std::min<uint32_t>(std::max<uint32_t>(p->queue_len, 1), 16);
     c->batch_reads = p->batch_reads ? p->batch_reads : (1u << 18);
     c->dev = p->device;
+    {
+        const uint64_t want = p->table_slots ? p->table_slots : (1ull << 24);
+        uint64_t pow2 = 1; while (pow2 < want && pow2 < (1ull << 33)) pow2 <<= 1;
+        if (pow2 > (1ull << 32)) return fail(VF_EINVAL, "table_slots too large");
+        c->table_slots = pow2;
+    }
 
     // can the 2-bit fast path hold these adapters and scores?  (else every read goes byte-wise)
     auto small = [](int32_t v) { return v >= -127 && v <= 127; };
@@ -337,7 +334,6 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     HIP_TRY(hipSetDevice(c->dev));
     HIP_TRY(hipStreamCreateWithFlags(&c->main_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->clear_event, hipEventDisableTiming));
-    if ((rc = c->main_lane.init())) return rc;
     if (const char *e = getenv("VFIND_RES_LANES")) c->n_res = (uint32_t)std::min(std::max(atoi(e), 1), (int)vf_ctx::kMaxResLanes);
     for (uint32_t i = 0; i < c->n_res; ++i) {
         ResLane &L = c->res[i];
@@ -346,7 +342,6 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
         L.chunk_row = 17 + i;
         if ((rc = L.h_entries.ensure(1))) return rc;
         *L.h_entries.p = 0;
-        if ((rc = L.lane.init())) return rc;
     }
 
     // adapters on the device (byte-wise kernel)
@@ -373,10 +368,6 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     }
 
     // count table
-    uint64_t slots = p->table_slots ? p->table_slots : (1ull << 24);
-    uint64_t pow2 = 1; while (pow2 < slots) pow2 <<= 1;
-    if (pow2 > (1ull << 32)) return fail(VF_EINVAL, "table_slots too large");
-    c->table_slots = pow2;
     c->arena_dwords = (p->arena_bytes ? p->arena_bytes : (1ull << 30)) / 4;
     if ((rc = c->t_slots.ensure(c->table_slots * 4))) return rc;
     if ((rc = c->t_counts.ensure(c->table_slots * kXcds))) return rc;
@@ -391,14 +382,13 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     if ((rc = table_clear_locked(c.get(), true))) return rc;
 
     for (uint32_t i = 0; i < c->queue_len; ++i) {
-        std::unique_ptr<Slot> s(new Slot);
+        c->slots.emplace_back(new Slot);                    // owned by the context first: a failure below frees it with the rest
+        Slot *s = c->slots.back().get();
         s->index = i;
         HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
-        if ((rc = s->lane.init())) return rc;
         if ((rc = s->h_entries.ensure(1))) return rc;
         *s->h_entries.p = 0;
-        c->slots.push_back(std::move(s));
     }
     *out = c.release();
     return VF_OK;
@@ -416,20 +406,19 @@ extern "C" void vf_ctx_destroy(vf_ctx *c) {
         s->h_spans.release();
         s->h_text.release(); s->d_text.release(); s->d_tile_cnt.release(); s->d_tile_off.release(); s->d_line_end.release();
         s->d_info.release(); s->d_gen_start.release(); s->d_gen_len.release(); s->h_info.release();
-        s->lane.destroy(); s->h_entries.release();
+        s->h_entries.release();
         if (s->done) (void)hipEventDestroy(s->done);
         if (s->stream) (void)hipStreamDestroy(s->stream);
     }
     for (int i = 0; i < vf_ctx::kMaxResLanes; ++i) {
         ResLane &L = c->res[i];
-        L.ws.release(); L.lane.destroy(); L.h_entries.release();
+        L.ws.release(); L.h_entries.release();
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
     c->exp_refs.release(); c->exp_counts.release();
     c->t_slots.release(); c->t_counts.release(); c->t_arena.release(); c->t_counters.release(); c->t_chunks.release();
     c->d_adapters.release();
-    c->main_lane.destroy();
     if (c->clear_event) (void)hipEventDestroy(c->clear_event);
     if (c->main_stream) (void)hipStreamDestroy(c->main_stream);
     delete c;
@@ -480,15 +469,16 @@ static int sync_all_streams(vf_ctx *c) {
 // every (stream row, workgroup) that has not taken an arena chunk yet may take one for a single key
 static inline uint64_t arena_slack(const vf_ctx *c) { return (uint64_t)(c->queue_len + vf_ctx::kMaxResLanes + 1) * kMaxGrid * kChunk; }
 
-// grows until (entries + extra) fits in half the slots; extra = reads about to be submitted (each may be a
-// new key).  Takes the table lock exclusively: no submitter is enqueueing while the table is swapped.
-static int table_grow_locked(vf_ctx *c, bool use_unenqueued, uint64_t extra) {
+// grows until (entries + extra) fits in half the slots and the arena has room for extra_arena more dwords; extra =
+// reads about to be submitted, or a peer's entries about to be merged (each may be a new key).  Re-inserted LONG keys
+// keep their arena offsets (k_rehash), so growth itself takes no arena room.  Takes the table lock exclusively: no
+// submitter is enqueueing while the table is swapped.
+static int table_grow_locked(vf_ctx *c, bool use_unenqueued, uint64_t extra, uint64_t extra_arena = 0) {
     std::unique_lock<std::shared_mutex> lk(c->table_mu);
     int rc;
     if ((rc = sync_all_streams(c))) return rc;
     uint64_t h[C_NUM];
     HIP_TRY(hipMemcpy(h, c->t_counters.p, sizeof(h), hipMemcpyDeviceToHost));
-    uint64_t extra_arena = 0;
     if (use_unenqueued) { std::lock_guard<std::mutex> g(c->cap_mu); extra = c->unenqueued; extra_arena = c->unenqueued_arena; }
     // key arena: offsets stay valid, so growing is a copy
     if (extra_arena) {
@@ -566,7 +556,7 @@ static int reserve_capacity(vf_ctx *c, CapacityTicket &t, uint64_t n, uint64_t a
 // ------------------------------------------------------------------------------------------------
 // device path over one packed batch (rows/lens already in HBM)
 // ------------------------------------------------------------------------------------------------
-static int run_packed(vf_ctx *c, hipStream_t st, Lane &lane, uint32_t chunk_row, Workspace &ws, const uint32_t *d_rows, int W,
+static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &ws, const uint32_t *d_rows, int W,
                       const uint16_t *d_lens, uint64_t n, short2 *d_spans, bool count, uint64_t *h_entries) {
     if (n == 0) return VF_OK;
     if (n > 0xFFFFFFF0ull) return fail(VF_EINVAL, "batch too large (max 2^32-16 reads per submission)");
@@ -750,7 +740,7 @@ static int submit_chunk(vf_ctx *c, const uint8_t *base, const ReadRef *reads, ui
         if ((rc = s->ws.ensure(nf))) return rc;
         HIP_TRY(hipMemcpyAsync(s->d_rows.p, s->h_rows.p, (size_t)nf * W * 4, hipMemcpyHostToDevice, s->stream));
         HIP_TRY(hipMemcpyAsync(s->d_lens.p, s->h_lens.p, nf * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
-        if ((rc = run_packed(c, s->stream, s->lane, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, nf, s->ws.spans.p, !spans_mode, s->h_entries.p))) return rc;
+        if ((rc = run_packed(c, s->stream, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, nf, s->ws.spans.p, !spans_mode, s->h_entries.p))) return rc;
     }
     if (ng) {
         if ((rc = run_generic(c, *s, ng, gbytes, gmax, !spans_mode, spans_mode))) return rc;
@@ -857,7 +847,7 @@ extern "C" int vf_submit_packed(vf_ctx *c, const uint32_t *rows, uint32_t W, con
         if ((rc = s->ws.ensure(m))) return rc;
         HIP_TRY(hipMemcpyAsync(s->d_rows.p, s->h_rows.p, (size_t)m * W * 4, hipMemcpyHostToDevice, s->stream));
         HIP_TRY(hipMemcpyAsync(s->d_lens.p, s->h_lens.p, m * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
-        if ((rc = run_packed(c, s->stream, s->lane, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, m, s->ws.spans.p, true, s->h_entries.p))) return rc;
+        if ((rc = run_packed(c, s->stream, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, m, s->ws.spans.p, true, s->h_entries.p))) return rc;
         HIP_TRY(hipEventRecord(s->done, s->stream));
         s->in_flight = true;
         c->n_reads += m;
@@ -878,7 +868,7 @@ extern "C" int vf_process_device_packed(vf_ctx *c, const void *d_rows, uint32_t 
     std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
     if ((rc = L.ws.ensure(n))) return rc;
     short2 *spans = d_spans ? (short2 *)d_spans : L.ws.spans.p;
-    if ((rc = run_packed(c, L.stream, L.lane, L.chunk_row, L.ws, (const uint32_t *)d_rows, (int)W, (const uint16_t *)d_lens, n, spans, true, L.h_entries.p))) return rc;
+    if ((rc = run_packed(c, L.stream, L.chunk_row, L.ws, (const uint32_t *)d_rows, (int)W, (const uint16_t *)d_lens, n, spans, true, L.h_entries.p))) return rc;
     HIP_TRY(hipEventRecord(L.done, L.stream));
     L.in_flight = true;
     c->n_reads += n;
@@ -983,13 +973,34 @@ extern "C" int vf_table_export(vf_ctx *c, void *d_dst, uint64_t capacity, uint64
     return VF_OK;
 }
 
+// header of an exported table as a peer sent it: checked without overflow before anything is sized from it
+static int blob_header_ok(const uint64_t hdr[2], uint64_t nbytes) {
+    if (nbytes < 16) return fail(VF_EINVAL, "blob too small");
+    const uint64_t room = nbytes - 16;
+    if (hdr[0] > room / 16 || hdr[1] > (room - hdr[0] * 16) / 4) return fail(VF_EINVAL, "blob truncated");
+    return VF_OK;
+}
+
 extern "C" int vf_table_merge(vf_ctx *c, const void *d_blob, uint64_t nbytes) {
     if (!c || !d_blob) return fail(VF_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(c->dev));
     if (nbytes < 16) return fail(VF_EINVAL, "blob too small");
     uint64_t hdr[2];
     HIP_TRY(hipMemcpy(hdr, d_blob, 16, hipMemcpyDeviceToHost));
-    if (blob_bytes(hdr[0], hdr[1]) > nbytes) return fail(VF_EINVAL, "blob truncated");
+    int rc;
+    if ((rc = blob_header_ok(hdr, nbytes))) return rc;
+    // every peer entry may be a new key (and every key dword may belong to a LONG key): make room first, exactly as a
+    // streaming submit does -- a table sized for one rank's keys would otherwise fill up under seven peers' tables
+    {
+        uint64_t cur;
+        { std::lock_guard<std::mutex> g(c->cap_mu); cur = c->upper_entries; }
+        if ((cur + hdr[0]) * 2 > c->table_slots || hdr[1]) {
+            if ((rc = table_grow_locked(c, false, hdr[0], hdr[1]))) return rc;
+        }
+        std::lock_guard<std::mutex> g(c->cap_mu);
+        c->upper_entries += hdr[0]; c->upper_arena += hdr[1];
+    }
+    std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
     const uint8_t *b = (const uint8_t *)d_blob;
     HIP_TRY(launch_merge(c->main_stream, c->tab, (const uint64_t *)(b + 16), (const uint64_t *)(b + 16 + hdr[0] * 8),
                          (const uint32_t *)(b + 16 + hdr[0] * 16), hdr[0]));
@@ -1093,7 +1104,7 @@ extern "C" int vf_stats_get(vf_ctx *c, vf_stats *o) {
     o->reads = c->n_reads; o->reads_generic = c->n_generic;
     o->dp_prefix = h[C_DP_PREFIX]; o->dp_suffix = h[C_DP_SUFFIX];
     o->accepted = h[C_ACCEPTED]; o->counted = h[C_COUNTED]; o->insert_path = h[C_SLOW];
-    o->table_entries = h[C_ENTRIES]; o->arena_dwords = h[C_KEY_DWORDS];
+    o->table_entries = h[C_ENTRIES]; o->arena_dwords = h[C_KEY_DWORDS]; o->arena_top = h[C_ARENA_TOP];
     o->ms_scan = c->ms[K_SCAN]; o->ms_filter = c->ms[K_FILTER]; o->ms_dp_window = c->ms[K_DPW]; o->ms_dp_rest = c->ms[K_DPREST];
     o->ms_finish = c->ms[K_FIN]; o->ms_generic = c->ms[K_GEN];
     o->launches_scan = c->launches[K_SCAN]; o->launches_filter = c->launches[K_FILTER];
@@ -1211,7 +1222,7 @@ int vf_internal_submit_text(vf_ctx *c, const TextSpan *spans, size_t n_spans, bo
                               s->d_gen_start.p, s->d_gen_len.p, s->d_info.p, !c->fast_ok));
     c->n_reads += n;
     if (c->fast_ok) {
-        if ((rc = run_packed(c, s->stream, s->lane, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, n, s->ws.spans.p, true, s->h_entries.p))) return rc;
+        if ((rc = run_packed(c, s->stream, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, n, s->ws.spans.p, true, s->h_entries.p))) return rc;
     }
     {   // listed reads (non-ACGT bytes, longer than a row): byte-wise kernel over the same text, count known only on the device
         const uint32_t mmax = (uint32_t)std::max(c->pre.size(), c->suf.size());

@@ -1106,8 +1106,12 @@ __device__ __forceinline__ int arena_alloc(BlockTable &bt, const Table &t, uint3
 }
 
 // Finds key's slot, inserting the key if absent; returns kNoSlot on a capacity error.
+// have_off: arena offset the (LONG) key already occupies (table growth re-inserts entries whose keys stay where they
+// are), kNoOff = the key is copied into a fresh arena allocation.
+constexpr uint64_t kNoOff = ~0ull;
 template <class K>
-__device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTable &bt, const K &key, uint32_t kind, uint32_t len, bool active) {
+__device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTable &bt, const K &key, uint32_t kind, uint32_t len, bool active,
+                                                         uint64_t have_off = kNoOff) {
     uint32_t found = kNoSlot;
     const uint32_t nd = key_dwords(kind, len);
     const uint32_t meta = len | (kind << 16);
@@ -1167,10 +1171,10 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
                     found = slot;
                     done = true;
                 } else {
-                    uint64_t off = 0;
-                    const int rc = arena_alloc(bt, t, nd, off);
+                    uint64_t off = have_off;
+                    const int rc = have_off != kNoOff ? (int)kAllocOk : arena_alloc(bt, t, nd, off);
                     if (rc == kAllocOk) {
-                        key.each(nd, [&](uint32_t d, uint32_t v) { st_agent(&t.arena[off + d], v); });
+                        if (have_off == kNoOff) key.each(nd, [&](uint32_t d, uint32_t v) { st_agent(&t.arena[off + d], v); });
                         st_agent(kw, (unsigned long long)off);
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         st_agent(reinterpret_cast<unsigned long long *>(sp), (unsigned long long)(w0mine | kW0Ready));
@@ -1228,8 +1232,9 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
 }
 
 template <class K>
-__device__ __forceinline__ void table_add(const Table &t, BlockTable &bt, const K &key, uint32_t kind, uint32_t len, uint64_t cnt, bool active) {
-    const uint32_t slot = table_find_or_insert(t, bt, key, kind, len, active);
+__device__ __forceinline__ void table_add(const Table &t, BlockTable &bt, const K &key, uint32_t kind, uint32_t len, uint64_t cnt, bool active,
+                                          uint64_t have_off = kNoOff) {
+    const uint32_t slot = table_find_or_insert(t, bt, key, kind, len, active, have_off);
     if (slot != kNoSlot) count_add(t, xcc_id(), slot, (unsigned long long)cnt);
 }
 
@@ -1928,7 +1933,7 @@ __global__ __launch_bounds__(kBlock) void k_merge(Table t, const uint64_t *__res
     block_table_end(bt, t);
 }
 
-// every entry of `from` re-inserted into `to` (table growth); both share arena, counters and chunks
+// every entry of `from` re-inserted into `to` (table growth); both share arena, counters and chunks; arena keys stay in place
 __global__ __launch_bounds__(kBlock) void k_rehash(Table from, Table to) {
     __shared__ BlockTable bt;
     block_table_begin(bt, to);
@@ -1952,7 +1957,9 @@ __global__ __launch_bounds__(kBlock) void k_rehash(Table from, Table to) {
             }
         }
         const uint32_t meta = (uint32_t)(w0 >> 32) & 0x3FFFFu;
-        table_add(to, bt, MemKey{kp, 1ull}, meta >> 16, meta & 0xFFFFu, cnt, live);
+        // a LONG key keeps its place in the arena (both tables share it): re-inserting it through arena_alloc doubled
+        // the arena's fill with every growth and the old copies were never reclaimed
+        table_add(to, bt, MemKey{kp, 1ull}, meta >> 16, meta & 0xFFFFu, cnt, live, (live && (w0 & kW0Long)) ? off : kNoOff);
     }
     __syncthreads();
     block_table_end(bt, to);
@@ -2086,12 +2093,14 @@ hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint1
     } while (0)
     switch (W) {
     case 10: {
+#ifdef VF_FINISH_ABLATION      // diagnosis build only (make ablation): these variants give wrong counts by construction
         static const int dbg = [] { const char *v = getenv("VFIND_FINISH_DBG"); return v ? atoi(v) : 0; }();
-        if (dbg == 1) hipLaunchKernelGGL((k_finish<10, 2, false, 1>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t);
-        else if (dbg == 2) hipLaunchKernelGGL((k_finish<10, 2, false, 2>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t);
-        else if (dbg == 3) hipLaunchKernelGGL((k_finish<10, 2, false, 3>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t);
-        else if (dbg == 4) hipLaunchKernelGGL((k_finish<10, 2, false, 4>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t);
-        else if (u2) VF_FINISH(10, 2); else VF_FINISH(10, 1);
+        if (dbg == 1) { hipLaunchKernelGGL((k_finish<10, 2, false, 1>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t); break; }
+        if (dbg == 2) { hipLaunchKernelGGL((k_finish<10, 2, false, 2>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t); break; }
+        if (dbg == 3) { hipLaunchKernelGGL((k_finish<10, 2, false, 3>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t); break; }
+        if (dbg == 4) { hipLaunchKernelGGL((k_finish<10, 2, false, 4>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t); break; }
+#endif
+        if (u2) VF_FINISH(10, 2); else VF_FINISH(10, 1);
         break;
     }
     case 20: VF_FINISH(20, 1); break;

@@ -177,7 +177,7 @@ inline void resolve_symbols(const uint16_t *s, size_t n, const uint8_t *W, uint8
 }
 
 struct OutPiece { uint8_t *buf; size_t n, nl; };
-struct Resolved { std::vector<OutPiece> pieces; uint32_t crc = 0; uint64_t len = 0; };
+struct Resolved { std::vector<OutPiece> pieces; uint32_t crc = 0; uint64_t len = 0; bool oom = false; };
 
 }  // namespace
 
@@ -198,7 +198,8 @@ bool inflate_member_parallel(const uint8_t *in, const uint8_t *in_end, unsigned 
     std::vector<uint8_t> window;                           // the (up to) 32 KiB of text in front of cur
     uint32_t crc = 0;
     uint64_t total = 0;
-    bool aborted = false;
+    bool aborted = false, out_of_memory = false;
+    static const char *const kOom = "out of memory: no buffer for inflated text";
 
     std::unique_ptr<Core8> core8(new Core8);
     std::vector<std::unique_ptr<DeflateCore<uint16_t>>> cores16;
@@ -221,6 +222,7 @@ bool inflate_member_parallel(const uint8_t *in, const uint8_t *in_end, unsigned 
         pending.pop_front();
         crc = crc32_join(crc, r.crc, r.len);
         total += r.len;
+        if (r.oom) { aborted = true; out_of_memory = true; }
         for (auto &pc : r.pieces) {
             if (aborted) { io.drop_buffer(pc.buf); continue; }
             if (!io.put_piece(pc.buf, pc.n, pc.nl)) aborted = true;
@@ -238,12 +240,13 @@ bool inflate_member_parallel(const uint8_t *in, const uint8_t *in_end, unsigned 
     auto exact_until = [&](uint64_t stop_bit, Core8::Status &st) -> bool {
         st = Core8::kBoundary;
         if (cur >= stop_bit) return true;
-        if (!emit_pending(true)) { *err = "aborted"; return false; }
+        if (!emit_pending(true)) { *err = out_of_memory ? kOom : "aborted"; return false; }
         core8->begin(base, in_end, cur);
         core8->set_history(window.data(), window.size());
         core8->set_stop_bit(stop_bit);
         for (;;) {
             uint8_t *buf = io.get_buffer();
+            if (!buf) { *err = "out of memory: no buffer for inflated text"; return false; }
             size_t got = 0;
             st = core8->run(buf, io.piece_bytes, &got);
             if (got) {
@@ -327,6 +330,7 @@ bool inflate_member_parallel(const uint8_t *in, const uint8_t *in_end, unsigned 
             size_t at = 0;
             while (at < sym->n) {
                 uint8_t *buf = io.get_buffer();
+                if (!buf) { r.oom = true; break; }           // reported by the coordinator (emit_front)
                 const size_t take = std::min(io.piece_bytes, sym->n - at);
                 const uint16_t *s = sym->p + at;
                 resolve_symbols(s, take, W, buf);
@@ -337,9 +341,9 @@ bool inflate_member_parallel(const uint8_t *in, const uint8_t *in_end, unsigned 
             r.len = sym->n;
             return r;
         }));
-        if (!emit_pending(false)) { *err = "aborted"; ok = false; break; }
+        if (!emit_pending(false)) { *err = out_of_memory ? kOom : "aborted"; ok = false; break; }
     }
-    if (ok && !emit_pending(true)) { *err = "aborted"; ok = false; }
+    if (ok && !emit_pending(true)) { *err = out_of_memory ? kOom : "aborted"; ok = false; }
     if (!ok) {
         while (!pending.empty()) { aborted = true; (void)emit_front(); }
         return false;
