@@ -32,3 +32,45 @@ def test_model_detects_a_misplaced_band(monkeypatch):
             ran += 1
             bad += not good
     assert bad > 0
+
+
+def test_block_filter_classes_equal_full_dp():
+    """the block filter (k_bfilter): copies of kerr_lo + 1 disjoint adapter blocks, a diagonal certified
+    at Hamming distance <= 1, band [dmin - K, dmax + K] of 5 or 10 diagonals -- restated in tests/tools/band_model.py
+    and compared with the full-matrix DP on random tasks (substitutions, indels, flanks, cut reads, second copies,
+    stray block copies, repetitive adapters, random scoring schemes)"""
+    rng = random.Random(20261005)
+    ran, stats = 0, {}
+    while ran < 250:
+        good = band_model.block_case(rng, stats)
+        if good is None:
+            continue
+        ran += 1
+        assert good
+    assert stats.get(band_model.KBAND_N, 0) > 50 and stats.get(band_model.KBAND, 0) > 20
+
+
+def test_block_model_detects_a_band_that_is_too_narrow(monkeypatch):
+    """with K - 1 in the place of K (a band one diagonal short on either side) the model must disagree with the full DP
+    on some tasks: gapped optimal alignments leave the narrower band"""
+    real = band_model.block_filter
+
+    def narrow(ad, read, K, plan, row_bases):
+        got = real(ad, read, K, plan, row_bases)
+        if got is None:
+            return None
+        kband, av = got
+        return kband - 2, av + 1
+    monkeypatch.setattr(band_model, "block_filter", narrow)
+    rng = random.Random(11)
+    ran = bad = 0
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        while ran < 400:
+            good = band_model.block_case(rng)
+            if good is None:
+                continue
+            ran += 1
+            bad += not good
+    assert bad > 0

@@ -720,5 +720,5 @@ def test_baseline_config_shapes_million_reads(name, kw, n):
         e.process_device(d_rows.data_ptr(), rows.shape[1], d_lens.data_ptr(), n)
         got = e.finish_dict()
         st = e.stats()
-    assert got == want and len(got) > 10000
+    assert got == want and len(got) > 5000
     assert st["dp_prefix"] > (500_000 if name == "cfg4" else 50_000)

@@ -66,8 +66,8 @@ def clusters(det_cols, gap):
     return ncl, c
 
 
-def banded(q, r, av, match, mismatch, gopen, gext):
-    """dp_banded restated: cells are (score, length); returns (score, length)"""
+def banded(q, r, av, match, mismatch, gopen, gext, KBAND=KBAND):
+    """dp_banded<M, B> restated (B = KBAND diagonals): cells are (score, length); returns (score, length)"""
     m, n = len(q), len(r)
     KT = m + KBAND - 1
     H = [(0, 0)] * m           # column 0 of the read
@@ -176,6 +176,132 @@ def one_case(rng):
     return good
 
 
+# ---- the block filter (k_bfilter): class N / class 0 without a Myers pass --------------------------------------
+KBAND_N = 5
+
+
+def block_plan(m, K):
+    """K + 1 disjoint adapter blocks (host: fill_dp): stretches of m // (K+1) bases (the first m % (K+1) one longer),
+    the first min(stretch, 8) bases of each; None when a block would be shorter than 5 bases or K + 1 > 4"""
+    nb = K + 1
+    if K < 1 or nb > 4:
+        return None
+    base, rem = divmod(m, nb)
+    offs, lens, o = [], [], 0
+    for b in range(nb):
+        ln = base + (1 if b < rem else 0)
+        offs.append(o)
+        lens.append(min(ln, 8))
+        o += ln
+    return (offs, lens) if min(lens) >= 5 else None
+
+
+def block_filter(ad, read, K, plan, row_bases):
+    """k_bfilter restated.  Returns None (task goes on to the Myers filter) or (band width class, av)."""
+    m, n = len(ad), len(read)
+    offs, lens = plan
+    row = list(read) + [0] * (row_bases + 48 - n)          # the packed row is zero padded ('A')
+    diags = []
+    for o, ln in zip(offs, lens):
+        for q in range(row_bases):                           # every start position of the row, as the kernel's masks hold them
+            if row[q:q + ln] == ad[o:o + ln]:
+                if q < o:
+                    return None                              # a copy whose adapter would start left of the read: not handled here
+                diags.append(q - o)
+    if not diags:
+        return None
+    dmin, dmax = min(diags), max(diags)
+    if dmax + m > n:
+        return None                                          # a copy (or padding) whose adapter would run past the read end
+    def ham(d):
+        return sum(a != b for a, b in zip(ad, read[d:d + m]))
+    if not (ham(dmin) <= 1 or (dmax != dmin and ham(dmax) <= 1)):
+        return None                                          # no column with unit edit distance <= 1 certified
+    width = dmax - dmin + 2 * K + 1
+    if width <= KBAND_N:
+        return KBAND_N, dmin - K
+    if width <= KBAND:
+        return KBAND, dmin - K
+    return None
+
+
+def block_case(rng, stats=None):
+    """one random task through the block filter; None = not classified by it, else True/False = banded DP == full DP"""
+    match = rng.choice([1, 2, 3, 3, 3, 4, 5])
+    mismatch = rng.choice([-4, -3, -2, -2, -2, -1, 0])
+    gopen = rng.choice([0, 2, 3, 5, 5, 5, 8])
+    gext = rng.choice([1, 2, 2, 2, 3, 4])
+    m = rng.randint(10, 32)
+    acc = rng.choice([0.5, 0.6, 0.7, 0.75, 0.75, 0.8, 0.9])
+    T = int(acc * match * m // 1) + 1
+    ad = [rng.randrange(4) for _ in range(m)]
+    if rng.random() < 0.15:                                  # repetitive adapters: blocks that look alike, homopolymer runs
+        u = [rng.randrange(4) for _ in range(rng.randint(1, 4))]
+        ad = (u * m)[:m]
+        for _ in range(rng.randint(0, 3)):
+            ad[rng.randrange(m)] = rng.randrange(4)
+    cp = list(ad)
+    for _ in range(rng.choice([1, 1, 1, 1, 1, 2, 2, 3])):
+        t = rng.random()
+        p = rng.randrange(len(cp))
+        if t < 0.7:
+            cp[p] = (cp[p] + rng.randint(1, 3)) % 4
+        elif t < 0.85:
+            cp.insert(p, rng.randrange(4))
+        elif len(cp) > 2:
+            del cp[p]
+    flank = [rng.randrange(4) for _ in range(rng.choice([0, 0, 0, 1, 2, 3, 5, 9, 17, 40]))]
+    tail = [rng.randrange(4) for _ in range(rng.choice([0, 0, 0, 1, 2, 3, 7, 20, 60]))]
+    read = flank + cp + tail
+    if rng.random() < 0.15:
+        read = read[rng.randint(1, 3):]
+    if rng.random() < 0.15:
+        read = read[: len(read) - rng.randint(1, 3)]
+    if rng.random() < 0.15:                                  # a second copy, close by or far away, intact or damaged
+        cp2 = list(ad)
+        for _ in range(rng.randint(0, 3)):
+            cp2[rng.randrange(m)] = rng.randrange(4)
+        read = read + [rng.randrange(4) for _ in range(rng.choice([0, 1, 2, 4, 9, 30]))] + cp2[rng.randint(0, 3):]
+    if rng.random() < 0.1:                                   # a stray copy of one block
+        o = rng.randrange(max(m - 7, 1))
+        at = rng.randrange(len(read) + 1)
+        read = read[:at] + ad[o:o + 7] + read[at:]
+    n = len(read)
+    if n == 0 or n > 640:
+        return None
+    kerr = max_unit_errors(T, m, match, mismatch, gopen, gext)
+    if kerr is None or kerr < 1 or m + kerr > 48:
+        return None
+    c_max = max(match, match - mismatch, match + max(gopen, gext))
+    T_lo = max(T, match * m - c_max)
+    k_lo = max_unit_errors(T_lo, m, match, mismatch, gopen, gext)
+    if k_lo is None or not (1 <= k_lo < kerr):
+        return None
+    plan = block_plan(m, k_lo)
+    if plan is None:
+        return None
+    row_bases = 160 if n <= 160 else 320 if n <= 320 else 640
+    cls = block_filter(ad, read, k_lo, plan, row_bases)
+    if cls is None:
+        return None
+    kband, av = cls
+    letters = b"ACGT"
+    qb = bytes(letters[x] for x in ad)
+    rb = bytes(letters[x] for x in read)
+    if rb.find(qb) >= 0:
+        return None                                          # an exact copy: the scan takes the read, no alignment task exists
+    fs, fl, _, _ = pyref.sg_stats_py(qb, rb, match, mismatch, gopen, gext)
+    bs, bl = banded(ad, read, av, match, mismatch, gopen, gext, kband)
+    ok_full, ok_band = fs >= T, bs >= T
+    good = ok_full == ok_band and (not ok_full or (fs == bs and fl == bl))
+    if stats is not None:
+        stats[kband] = stats.get(kband, 0) + 1
+    if not good:
+        print("BLOCK MISMATCH", dict(match=match, mismatch=mismatch, gopen=gopen, gext=gext, T=T, kerr=kerr, k_lo=k_lo, av=av, kband=kband, plan=plan),
+              qb, rb, "full", (fs, fl), "band", (bs, bl))
+    return good
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -187,7 +313,16 @@ def main():
         ran += 1
         bad += not g
     print(f"{ran} class-0 tasks, {bad} mismatches")
-    return 1 if bad else 0
+    ranb = badb = 0
+    stats = {}
+    while ranb < cases:
+        g = block_case(rng, stats)
+        if g is None:
+            continue
+        ranb += 1
+        badb += not g
+    print(f"{ranb} block-filter tasks ({stats}), {badb} mismatches")
+    return 1 if bad or badb else 0
 
 
 if __name__ == "__main__":

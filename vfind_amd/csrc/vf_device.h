@@ -39,6 +39,10 @@ struct DpParams {
     int32_t kerr_lo;      // the same bound for a task whose best end column has unit edit distance 1; <0 = not tighter
     uint32_t eq_top[4];   // eq[c] moved to the top m bits, low 32-m bits set (Myers filter)
     uint32_t pv_init;     // top m bits set
+    // block filter (k_bfilter): kerr_lo + 1 disjoint adapter blocks, block b = bases [blk_off[b], blk_off[b] + blk_len[b]);
+    // nblk = 0: off (no tightened bound, a block shorter than 5 bases, or more than 4 blocks)
+    uint32_t nblk;
+    uint32_t blk_off[4], blk_len[4];
 };
 
 struct ScanParams {
@@ -103,14 +107,25 @@ struct BatchLists {        // per in-flight batch; lists are segmented per workg
     uint32_t *listW[4], *winW[4];     // filter output by class: 0 banded (+ first diagonal + kBandBias), 1..3 windowed (+ window a | b<<16)
     uint32_t *winW2;                  // second window of class-3 (two-window) tasks
     uint32_t *listF;                  // filter output: tasks only the full-width DP can take
-    uint32_t *cntP, *cntS, *cntW[4], *cntF;   // kMaxGrid entries each
-    uint32_t *tot;                    // [2][8]: tasks per class (0..3, 4 = full-width rest) of the prefix / suffix filter pass
+    uint32_t *listN, *winN;           // block-filter output: narrow-band tasks (+ first diagonal + kBandBias)
+    uint32_t *listR;                  // block-filter output: tasks it could not classify (the Myers filter takes them)
+    uint32_t *cntP, *cntS, *cntW[4], *cntF, *cntN, *cntR;   // kMaxGrid entries each
+    uint32_t *tot;                    // [2][8]: tasks per class (0..3, 4 = full-width rest, 5 = narrow band) of the prefix / suffix pass
     uint32_t grid, seg;               // from scan_geometry(n)
+};
+
+// the class lists of one filter pass as the stage functions of k_bmfilter take them
+struct ClassSet {
+    uint32_t *listN, *winN;           // narrow band (block filter)
+    uint32_t *listW[4], *winW[4];     // 0 banded, 1..3 windowed
+    uint32_t *winW2, *listF, *listR;  // second window, full width, rest (tasks the block filter left for the Myers pass)
 };
 
 void scan_geometry(uint64_t n, uint32_t *grid, uint32_t *seg);
 hipError_t launch_scan(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n,
                        const ScanParams &sp, short2 *spans, BatchLists bl);
+hipError_t launch_bmfilter(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
+                           BatchLists bl, uint64_t *counters);
 hipError_t launch_filter(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
                          short2 *spans, BatchLists bl, uint64_t *counters);
 hipError_t launch_dp_classes(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,

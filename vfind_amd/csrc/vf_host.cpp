@@ -90,24 +90,21 @@ template <typename T> struct PinBuf {
 
 struct Workspace {               // device scratch of one in-flight batch
     DevBuf<short2> spans;
-    DevBuf<uint32_t> listP, listS, listW[4], winW[4], winW2, listF, cnt;
+    DevBuf<uint32_t> listP, listS, listW[4], winW[4], winW2, listF, listN, winN, listR, cnt;
     int ensure(size_t n) {
         int rc;
         uint32_t g, seg;
         scan_geometry(n, &g, &seg);
+        const size_t e = (size_t)g * seg;
         if ((rc = spans.ensure(n))) return rc;
-        if ((rc = listP.ensure((size_t)g * seg))) return rc;
-        if ((rc = listS.ensure((size_t)g * seg))) return rc;
-        for (int q = 0; q < 4; ++q) {
-            if ((rc = listW[q].ensure((size_t)g * seg))) return rc;
-            if ((rc = winW[q].ensure((size_t)g * seg))) return rc;
-        }
-        if ((rc = winW2.ensure((size_t)g * seg))) return rc;
-        if ((rc = listF.ensure((size_t)g * seg))) return rc;
-        return cnt.ensure(7 * kMaxGrid + 16);
+        if ((rc = listP.ensure(e)) || (rc = listS.ensure(e)) || (rc = winW2.ensure(e)) || (rc = listF.ensure(e))) return rc;
+        if ((rc = listN.ensure(e)) || (rc = winN.ensure(e)) || (rc = listR.ensure(e))) return rc;
+        for (int q = 0; q < 4; ++q) if ((rc = listW[q].ensure(e)) || (rc = winW[q].ensure(e))) return rc;
+        return cnt.ensure(9 * kMaxGrid + 16);
     }
     void release() {
         spans.release(); listP.release(); listS.release(); listF.release(); winW2.release(); cnt.release();
+        listN.release(); winN.release(); listR.release();
         for (int q = 0; q < 4; ++q) { listW[q].release(); winW[q].release(); }
     }
 };
@@ -159,6 +156,7 @@ struct vf_ctx {
     bool skip_translation = false;
     bool fast_ok = false;
     bool filter_on = false;      // Myers pre-DP filter + windowed DP usable for these scores
+    bool block_filter = true;    // block filter in front of it (VFIND_BLOCK_FILTER=0 switches it off: A/B runs)
     uint32_t n_threads = 3, queue_len = 2, batch_reads = 1u << 18;
     ScanParams sp{};
     DpParams dpP{}, dpS{};
@@ -184,8 +182,8 @@ struct vf_ctx {
     int profiling = 0;                  // 0 off, 1 every kernel bracket, 2 the table kernel (k_finish) only
     std::mutex ev_mu;
     std::vector<EventPair> pending_events;
-    double ms[K_KINDS] = {0, 0, 0, 0, 0, 0};
-    uint64_t launches[K_KINDS] = {0, 0, 0, 0, 0, 0};
+    double ms[K_KINDS] = {};
+    uint64_t launches[K_KINDS] = {};
     // async error from worker threads
     // table growth: submitters hold it shared while they enqueue, table_grow exclusively
     std::shared_mutex table_mu;
@@ -270,6 +268,20 @@ static void fill_dp(DpParams &d, const std::string &ad, int64_t T, const vf_ctx 
         const int32_t k_lo = max_unit_errors(T_lo, ad.size(), c.match, c.mismatch, c.gopen, c.gext);
         if (k_lo >= 1 && k_lo < d.kerr) d.kerr_lo = k_lo;
     }
+    // block filter (k_bfilter): kerr_lo + 1 disjoint stretches of the adapter, the first min(stretch, 8) bases of each
+    d.nblk = 0;
+    for (int b = 0; b < 4; ++b) { d.blk_off[b] = 0; d.blk_len[b] = 0; }
+    if (d.kerr_lo >= 1 && d.kerr_lo <= 3) {
+        const uint32_t nb = (uint32_t)d.kerr_lo + 1u, base = d.m / nb, rem = d.m % nb;
+        uint32_t o = 0, shortest = 8;
+        for (uint32_t b = 0; b < nb; ++b) {
+            const uint32_t ln = base + (b < rem ? 1u : 0u);
+            d.blk_off[b] = o; d.blk_len[b] = std::min(ln, 8u);
+            shortest = std::min(shortest, d.blk_len[b]);
+            o += ln;
+        }
+        if (shortest >= 5) d.nblk = nb;                 // shorter blocks turn up by chance too often to be worth the pass
+    }
     const uint32_t up = 32u - d.m;                     // d.m in 1..32
     for (int q = 0; q < 4; ++q) d.eq_top[q] = up ? ((d.eq[q] << up) | ((1u << up) - 1u)) : d.eq[q];
     d.pv_init = up ? (0xFFFFFFFFu << up) : 0xFFFFFFFFu;
@@ -334,6 +346,7 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     HIP_TRY(hipSetDevice(c->dev));
     HIP_TRY(hipStreamCreateWithFlags(&c->main_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->clear_event, hipEventDisableTiming));
+    if (const char *e = getenv("VFIND_BLOCK_FILTER")) c->block_filter = atoi(e) != 0;
     if (const char *e = getenv("VFIND_RES_LANES")) c->n_res = (uint32_t)std::min(std::max(atoi(e), 1), (int)vf_ctx::kMaxResLanes);
     for (uint32_t i = 0; i < c->n_res; ++i) {
         ResLane &L = c->res[i];
@@ -564,7 +577,9 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
     bl.listP = ws.listP.p; bl.listS = ws.listS.p; bl.listF = ws.listF.p;
     bl.cntP = ws.cnt.p; bl.cntS = ws.cnt.p + kMaxGrid; bl.cntF = ws.cnt.p + 2 * kMaxGrid;
     bl.winW2 = ws.winW2.p;
-    bl.tot = ws.cnt.p + 7 * kMaxGrid;
+    bl.listN = ws.listN.p; bl.winN = ws.winN.p; bl.listR = ws.listR.p;
+    bl.cntN = ws.cnt.p + 7 * kMaxGrid; bl.cntR = ws.cnt.p + 8 * kMaxGrid;
+    bl.tot = ws.cnt.p + 9 * kMaxGrid;
     for (int q = 0; q < 4; ++q) { bl.listW[q] = ws.listW[q].p; bl.winW[q] = ws.winW[q].p; bl.cntW[q] = ws.cnt.p + (3 + q) * kMaxGrid; }
     scan_geometry(n, &bl.grid, &bl.seg);
     // counting mode skips the suffix alignment of a read whose prefix failed (same table, less work);
@@ -572,15 +587,18 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
     ScanParams sp = c->sp; DpParams dpP = c->dpP, dpS = c->dpS;
     sp.independent = dpP.independent = dpS.independent = count ? 0u : 1u;
     { Timed t(c, st, K_SCAN); HIP_TRY(launch_scan(st, W, d_rows, d_lens, n, sp, d_spans, bl)); }
-    // per adapter: Myers filter -> windowed DP (-> full-width DP for the rare over-long window), or the
-    // full-width DP alone when the scoring scheme gives the filter no usable edit bound
+    // per adapter: filter (block filter + Myers pass over what it leaves, one launch; the Myers pass alone where the scoring
+    // gives the block filter no bound) -> every task class of the DP in one launch; or the full-width DP alone when the
+    // scoring scheme gives no edit bound at all
     for (int role = 0; role < 2; ++role) {
         if (role == 0 ? c->skip_pre : c->skip_suf) continue;
         const DpParams &dp = role == 0 ? dpP : dpS;
         if (c->filter_on) {
-            // One consumer launch for all five task classes of the filter (k_dpall splits its grid by the class totals
-            // the filter leaves behind): no side stream, no fork/join events.
-            { Timed t(c, st, K_FILTER); HIP_TRY(launch_filter(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters)); }
+            {
+                Timed t(c, st, K_FILTER);
+                if (dp.nblk != 0 && c->block_filter) HIP_TRY(launch_bmfilter(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters));
+                else HIP_TRY(launch_filter(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters));
+            }
             { Timed t(c, st, K_DPW); HIP_TRY(launch_dp_classes(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters)); }
         } else {
             Timed t(c, st, K_DPREST);
@@ -877,9 +895,9 @@ extern "C" int vf_process_device_packed(vf_ctx *c, const void *d_rows, uint32_t 
     if (dbg_classes) {
         uint32_t tot[16];
         HIP_TRY(hipStreamSynchronize(L.stream));
-        HIP_TRY(hipMemcpy(tot, L.ws.cnt.p + 7 * kMaxGrid, sizeof(tot), hipMemcpyDeviceToHost));
-        fprintf(stderr, "vfind classes (banded, window, long window, two windows, full width): prefix %u %u %u %u %u  suffix %u %u %u %u %u\n",
-                tot[0], tot[1], tot[2], tot[3], tot[4], tot[8], tot[9], tot[10], tot[11], tot[12]);
+        HIP_TRY(hipMemcpy(tot, L.ws.cnt.p + 9 * kMaxGrid, sizeof(tot), hipMemcpyDeviceToHost));
+        fprintf(stderr, "vfind classes (narrow band, banded, window, long window, two windows, full width): prefix %u %u %u %u %u %u  suffix %u %u %u %u %u %u\n",
+                tot[5], tot[0], tot[1], tot[2], tot[3], tot[4], tot[13], tot[8], tot[9], tot[10], tot[11], tot[12]);
     }
     return VF_OK;
 }

@@ -66,11 +66,22 @@ __device__ __forceinline__ void wave_count_lds(uint32_t *s_counter, bool pred) {
 // ------------------------------------------------------------------------------------------------
 // row load: W dwords per read, rows are only 8-byte aligned (W*4 = 40/80/160 bytes)
 // ------------------------------------------------------------------------------------------------
+// VF_ROWS_NT=1 loads the packed rows non-temporally (tried so that the 420 MB row stream would not push the count table out
+// of the 256 MiB Infinity Cache): measured slower everywhere -- cfg 2 1.03 against 0.95 ms per step, k_scan 0.38 against
+// 0.33 ms: the rows themselves are re-read by the next kernel of the batch and want the cache
+#ifndef VF_ROWS_NT
+#define VF_ROWS_NT 0
+#endif
 template <int W> __device__ __forceinline__ void load_row(const uint32_t *rows, uint64_t r, uint32_t (&x)[W + 2]) {
-    const uint2 *p = reinterpret_cast<const uint2 *>(rows + r * W);
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 *p = reinterpret_cast<const u32x2 *>(rows + r * W);
 #pragma unroll
     for (int i = 0; i < W / 2; ++i) {
-        uint2 v = p[i];
+#if VF_ROWS_NT
+        const u32x2 v = __builtin_nontemporal_load(p + i);
+#else
+        const u32x2 v = p[i];
+#endif
         x[2 * i] = v.x;
         x[2 * i + 1] = v.y;
     }
@@ -532,10 +543,21 @@ __device__ __forceinline__ void myers_column(uint32_t Eq, uint32_t &Pv, uint32_t
 // column loop has no divergent control flow at all.  The row is held in registers ten words (one
 // 40-byte chunk) at a time and the next chunk is fetched while the current one is scanned: a load per
 // word inside the loop made every word wait for global memory (59 % of the kernel's wave cycles).
+// first 10-word chunk of a task's row (zeros past the read's own words): the caller may fetch it a trip ahead
+__device__ __forceinline__ void myers_first_chunk(const uint32_t *__restrict__ row, int n, uint32_t (&xn)[10]) {
+    const int nwords = (n + 15) >> 4;
+    const uint2 *p = reinterpret_cast<const uint2 *>(row);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        uint2 v = make_uint2(0u, 0u);
+        if (2 * i < nwords) v = p[i];
+        xn[2 * i] = v.x; xn[2 * i + 1] = v.y;
+    }
+}
 template <int W>
 __device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int n, const DpParams &dp, const uint2 *s_eq2,
-                                           Clusters &cl) {
-    constexpr int CW = 10;                             // words per chunk
+                                           Clusters &cl, uint32_t (&xn)[10]) {
+    constexpr int CW = 10;                             // words per chunk (xn holds chunk 0 on entry)
     uint32_t Pv = dp.pv_init, Mv = 0u;
     int sc = (int)dp.m - dp.kerr - 1;                  // unit edit distance minus (kerr + 1): negative <=> detected
     const int gap = (int)dp.m + dp.kerr;
@@ -556,7 +578,6 @@ __device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int
         else if (cl.ncl == 1) { if (jf - cl.jmax1 > gap) { cl.ncl = 2; cl.jmin2 = jf; cl.jmax2 = jl; } else cl.jmax1 = jl; }
         else if (cl.ncl == 2) { if (jf - cl.jmax2 > gap) cl.ncl = 3; else cl.jmax2 = jl; }
     };
-    uint32_t xn[CW];
     auto fetch = [&](int c) {                          // chunk c of this lane's row (zeros past its own words)
         const uint2 *p = reinterpret_cast<const uint2 *>(row + c * CW);
 #pragma unroll
@@ -566,7 +587,6 @@ __device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int
             xn[2 * i] = v.x; xn[2 * i + 1] = v.y;
         }
     };
-    fetch(0);
     for (int c = 0; c * CW < nw_max; ++c) {
         uint32_t x[CW];
 #pragma unroll
@@ -611,8 +631,124 @@ __device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int
 }
 
 constexpr int kMaxWindow = 64;   // columns the windowed DP holds in registers (5 dwords incl. phase)
-constexpr int kBand = 10;        // diagonals the banded DP (dp_banded) computes
+constexpr int kBand = 10;        // diagonals the banded DP (dp_banded) computes for class 0
+constexpr int kBandN = 5;        // ... and for the narrow class of the block filter (one diagonal of block copies, +-2 unit edits)
 constexpr int kBandBias = 4096;  // class-0 window word = first diagonal + kBandBias
+
+// ------------------------------------------------------------------------------------------------
+// k_bfilter: the block filter, in front of the Myers pass.
+//
+// A task that has a column of unit edit distance <= 1 has an optimum S* >= T' = max(T, match*m - c_max), so every optimal
+// alignment has at most K = kerr_lo unit edits (host: fill_dp; mismatch, base in a gap, unaligned adapter end base).  The
+// adapter holds K + 1 disjoint blocks; an edit spoils one block at most, so every such alignment matches one block base
+// for base, without a gap inside: an exact copy of the block in the read, at read position q = d + blk_off on some
+// diagonal d = j - i.  With at most K gap edits in all, every cell of that alignment lies on diagonals [d - K, d + K].
+// So: find EVERY copy of every block (XOR-accumulate over the block's bases at every start position, the machinery of
+// k_scan's stage 1; shifts are by the base's index inside its block, so all blocks share them), take the hull
+// [dmin, dmax] of their diagonals; if the adapter at dmin or dmax differs from the read in at most one base (that
+// certifies the column of distance <= 1) the cells of all optimal alignments lie on [dmin - K, dmax + K]: a band of
+// dmax - dmin + 2K + 1 diagonals, class N when that is at most kBandN, class 0 (dp_banded at kBand) when at most kBand.
+// Everything else -- no copy at all (adapter-free reads, more than K edits), copies too far apart, a copy whose adapter
+// would overhang either read end, a single indel (no diagonal certifies) -- goes to listR for the Myers filter.
+// Exactness is the windowed DP's argument with T' in the place of T; tests/tools/band_model.py restates
+// the decision and the banded DP on the CPU against the full-matrix DP.
+// ------------------------------------------------------------------------------------------------
+// One task through the block filter.  x = the task's row (zero beyond the read), rowcol = a lane-private LDS column of
+// W + 2 words (stride kBlock): the certification reads three words of the row at a dynamic offset, which registers cannot
+// give and a global re-load pays a memory round trip for.  Result: toN / to0 (narrow / class-0 band, first diagonal in
+// win), neither = the Myers pass decides.
+template <int W, int NB>
+__device__ __forceinline__ void bf_classify(const uint32_t (&x)[W + 2], int n, bool valid, const DpParams &dp, uint32_t *rowcol,
+                                            bool &toN, bool &to0, uint32_t &win) {
+    const int m = (int)dp.m, K = dp.kerr_lo;
+    uint32_t maxlen = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) maxlen = max(maxlen, (uint32_t)b < dp.nblk ? dp.blk_len[b] : 0u);
+    // every copy of every block: acc slot p of block b stays 0 iff read[p + k] == block[k] for all k
+    uint32_t acc[NB][W];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int w = 0; w < W; ++w) acc[b][w] = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if ((uint32_t)k < maxlen) {               // wave-uniform
+            uint32_t xs[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) xs[w] = k ? funnel(x[w + 1], x[w], 2 * k) : x[w];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if ((uint32_t)b < dp.nblk && (uint32_t)k < dp.blk_len[b]) {
+                    const uint32_t bp = to_vgpr_u((uint32_t)((dp.pat >> (2u * (dp.blk_off[b] + (uint32_t)k))) & 3ull) * 0x55555555u);
+#pragma unroll
+                    for (int w = 0; w < W; ++w) acc[b][w] |= xs[w] ^ bp;
+                }
+            }
+        }
+    }
+    // copies as one bit per start position, moved from read positions to diagonals (q - blk_off) and united
+    uint32_t U[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) U[w] = 0;
+    uint32_t neg = 0;                             // a copy whose adapter would start left of the read
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if ((uint32_t)b < dp.nblk) {              // wave-uniform
+            uint32_t h[W + 2];
+#pragma unroll
+            for (int w = 0; w < W; ++w) h[w] = ~(acc[b][w] | (acc[b][w] >> 1)) & 0x55555555u;
+            h[W] = 0; h[W + 1] = 0;
+            const uint32_t off = dp.blk_off[b];   // < 32
+            const uint32_t lo_bits = 2u * min(off, 16u), hi_bits = off > 16u ? 2u * (off - 16u) : 0u;
+            neg |= h[0] & (lo_bits >= 32u ? 0xFFFFFFFFu : ((1u << lo_bits) - 1u));
+            neg |= h[1] & ((1u << hi_bits) - 1u);
+            const uint32_t bs = 2u * (off & 15u);
+            uint32_t sh[W + 1];
+#pragma unroll
+            for (int w = 0; w <= W; ++w) sh[w] = funnel(h[w + 1], h[w], bs);
+            if (off >= 16u) {                     // wave-uniform
+#pragma unroll
+                for (int w = 0; w < W; ++w) U[w] |= sh[w + 1];
+            } else {
+#pragma unroll
+                for (int w = 0; w < W; ++w) U[w] |= sh[w];
+            }
+        }
+    }
+    uint32_t dfirst = 0xFFFFFFFFu;
+    int dlast = -1;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        dfirst = min(dfirst, (((uint32_t)(__ffs((int)U[w]) - 1)) >> 1) + 16u * (uint32_t)w);
+        dlast = max(dlast, U[w] ? ((31 - __clz((int)U[w])) >> 1) + 16 * w : -1);
+    }
+    const bool any = valid && dlast >= 0;
+    const int dmin = any ? (int)dfirst : 0, dmax = any ? dlast : 0;
+    const bool inside = any && neg == 0u && dmax + m <= n;
+    // the column of unit edit distance <= 1: the adapter on diagonal dmin or dmax, at most one base different
+    bool cert = false;
+    if (__any(inside)) {
+        const uint64_t patmask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
+#pragma unroll
+        for (int w = 0; w < W + 2; ++w) rowcol[w * kBlock] = x[w];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int d = inside ? (e == 0 ? dmin : dmax) : 0;
+            const int idx = d >> 4;                       // <= W - 1 (d + m <= n <= 16 W)
+            const uint32_t bsh = 2u * (uint32_t)(d & 15);
+            const uint32_t d0 = rowcol[idx * kBlock], d1 = rowcol[(idx + 1) * kBlock], d2 = rowcol[(idx + 2) * kBlock];
+            const uint32_t lo = funnel(d1, d0, bsh), hi = funnel(d2, d1, bsh);
+            uint64_t diff = ((((uint64_t)hi << 32) | lo) ^ dp.pat) & patmask;
+            diff = (diff | (diff >> 1)) & 0x5555555555555555ull;
+            cert = cert || (inside && __popcll(diff) <= 1);
+        }
+    }
+    const int width = dmax - dmin + 2 * K + 1;
+    toN = cert && width <= kBandN;
+    to0 = cert && !toN && width <= kBand;
+    win = (uint32_t)(dmin - K + kBandBias);
+}
+
 // Task classes: tasks of similar trip count share waves (a wave runs its longest window).
 //   0 banded (dp_banded), 1..2 one window by length, 3 two disjoint windows, 4 anything else -> full-width DP
 __device__ __forceinline__ int window_class(const Clusters &cl, int a1, int a2, int base, int kerr) {
@@ -625,6 +761,8 @@ __device__ __forceinline__ int window_class(const Clusters &cl, int a1, int a2, 
     return 4;
 }
 
+// the Myers pass alone, over every task of the adapter's list (scoring schemes that give the block filter no bound, or
+// VFIND_BLOCK_FILTER=0)
 template <int W>
 __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens,
                                                    DpParams dp, short2 *__restrict__ spans, BatchLists bl,
@@ -637,7 +775,7 @@ __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ 
     uint32_t stat = 0;
     for (uint32_t b = blockIdx.x; b < bl.grid; b += gridDim.x) {
         const uint32_t ntask = cnt[b];
-        if (threadIdx.x < 5) s_c[threadIdx.x] = 0;
+        if (threadIdx.x < 5) s_c[threadIdx.x] = 0u;
         __syncthreads();
         const uint32_t n_round = (ntask + WAVE - 1) / WAVE * WAVE;
         const uint64_t seg0 = (uint64_t)b * bl.seg;
@@ -647,7 +785,9 @@ __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ 
             int n = 0;
             if (valid) { r = list[seg0 + t]; n = lens[r]; }
             Clusters cl;
-            myers_scan<W>(rows + (uint64_t)r * W, n, dp, s_eq2, cl);
+            uint32_t x0[10];
+            myers_first_chunk(rows + (uint64_t)r * W, n, x0);
+            myers_scan<W>(rows + (uint64_t)r * W, n, dp, s_eq2, cl, x0);
             const bool any = valid && cl.ncl > 0;
             if (valid && !any) (void)dp_commit(true, r, n, false, 0, dp, spans);
             const int base = (int)dp.m + dp.kerr;
@@ -684,6 +824,158 @@ __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ 
         if (threadIdx.x < 4) bl.cntW[threadIdx.x][b] = s_c[threadIdx.x];
         if (threadIdx.x == 4) bl.cntF[b] = s_c[4];
         if (threadIdx.x < 5 && s_c[threadIdx.x]) atomicAdd(&bl.tot[(dp.is_prefix ? 0u : 8u) + threadIdx.x], s_c[threadIdx.x]);
+        if (threadIdx.x == 5) bl.cntN[b] = 0;
+        stat += ntask;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && stat)
+        atomicAdd((unsigned long long *)&counters[dp.is_prefix ? C_DP_PREFIX : C_DP_SUFFIX], (unsigned long long)stat);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stages of k_bmfilter (block filter, then Myers pass over what it left), written as per-workgroup loops over a task
+// segment that fetch the task of the next trip while they work on the current one (task index two trips ahead, row one
+// trip ahead).
+// (Round 2 also built k_front: exact scan, both block filters and the prefix Myers pass as ONE persistent kernel, every
+// list workgroup-local.  It gave bit-identical results and took exactly as long as its parts -- 448 us against 439 us for
+// scan + 2 block filters + Myers pass on one batch lane -- because all workgroups walk through the stages in step, so
+// nothing overlaps; next to the other lane's k_finish it was slower, 1.04-1.15 against 0.93 ms per step, its 94 registers
+// leaving the scan stage fewer waves than k_scan's 72.  Removed again)
+// ------------------------------------------------------------------------------------------------
+// trips of one wave over a task list of the workgroup: lane l of wave w takes tasks w*64 + l + 256 i
+struct TripIter {
+    uint32_t t, ntask;
+    __device__ __forceinline__ TripIter(uint32_t ntask_) : t(threadIdx.x), ntask(ntask_) {}
+    __device__ __forceinline__ uint32_t trips() const {       // wave-uniform
+        const uint32_t wbase = threadIdx.x & ~(uint32_t)(WAVE - 1);
+        return ntask > wbase ? (ntask - wbase + kBlock - 1) / kBlock : 0u;
+    }
+};
+
+template <int W, int NB>
+__device__ __forceinline__ void front_bf_stage(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, const DpParams &dp,
+                                               const uint32_t *list, uint32_t ntask, const ClassSet &cs, uint64_t seg0, uint32_t *s_c,
+                                               uint32_t *rowcol) {
+    // the task index is fetched a trip ahead, the row is not: a second row in registers (12 more, 106 in all) cost the
+    // kernel two of its six waves per SIMD and made it slower than the plain loop
+    TripIter it(ntask);
+    const uint32_t ntrip = it.trips();
+    uint32_t t = it.t;
+    bool v_n = t < ntask;
+    uint32_t r_n = v_n ? list[seg0 + t] : 0u;
+    for (uint32_t i = 0; i < ntrip; ++i, t += kBlock) {
+        const uint32_t r = r_n;
+        const bool valid = v_n;
+        uint32_t x[W + 2];
+        int n = 0;
+        if (valid) { n = lens[r]; load_row<W>(rows, r, x); }
+        else {
+#pragma unroll
+            for (int k = 0; k < W + 2; ++k) x[k] = 0;
+        }
+        v_n = t + kBlock < ntask;
+        r_n = v_n ? list[seg0 + t + kBlock] : 0u;
+        bool toN, to0;
+        uint32_t win;
+        bf_classify<W, NB>(x, n, valid, dp, rowcol, toN, to0, win);
+        const bool toR = valid && !toN && !to0;
+        const uint32_t iN = wave_append(&s_c[0], toN);
+        if (toN) { cs.listN[seg0 + iN] = r; cs.winN[seg0 + iN] = win; }
+        const uint32_t i0 = wave_append(&s_c[1], to0);
+        if (to0) { cs.listW[0][seg0 + i0] = r; cs.winW[0][seg0 + i0] = win; }
+        const uint32_t iR = wave_append(&s_c[2], toR);
+        if (toR) cs.listR[seg0 + iR] = r;
+    }
+}
+
+// Myers filter over the nR tasks a block filter left in cs.listR of this workgroup's segment: classes 0..4 (s_my counts them,
+// s_my[0] starts at the number of class-0 tasks the block filter put into the segment) or "no alignment can pass".
+// Task index one trip ahead.
+template <int W>
+__device__ __forceinline__ void front_myers_stage(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, const DpParams &dp,
+                                                  short2 *__restrict__ spans, const ClassSet &cs, uint32_t nR, uint64_t seg0,
+                                                  uint32_t *s_my, const uint2 *s_eq2) {
+    TripIter it(nR);
+    const uint32_t ntrip = it.trips();
+    uint32_t t = it.t;
+    bool v_n = t < nR;
+    uint32_t r_n = v_n ? cs.listR[seg0 + t] : 0u;
+    for (uint32_t i = 0; i < ntrip; ++i, t += kBlock) {
+        const uint32_t r = r_n;
+        const bool valid = v_n;
+        const int n = valid ? (int)lens[r] : 0;
+        uint32_t x0[10];
+        myers_first_chunk(rows + (uint64_t)r * W, n, x0);
+        v_n = t + kBlock < nR;
+        r_n = v_n ? cs.listR[seg0 + t + kBlock] : 0u;
+        Clusters cl;
+        myers_scan<W>(rows + (uint64_t)r * W, n, dp, s_eq2, cl, x0);
+        const bool any = valid && cl.ncl > 0;
+        if (valid && !any) (void)dp_commit(true, r, n, false, 0, dp, spans);
+        const int base = (int)dp.m + dp.kerr;
+        const int a1 = max(0, cl.jmin1 - base), a2 = max(0, cl.jmin2 - base);
+        int cls = window_class(cl, a1, a2, base, dp.kerr);
+        int av = 0;
+        if (dp.kerr_lo >= 0 && cl.dmin <= 1 && cl.ncl == 1) {          // class 0 of the Myers filter (k_filter)
+            const int dl = dp.kerr - dp.kerr_lo;
+            const int lo = cl.jmin1 > 1 ? cl.jmin1 + dl : 1;
+            const int hi = cl.jmax1 < n ? cl.jmax1 - dl : n;
+            if (hi >= lo && hi - lo + 2 * dp.kerr_lo + 1 <= kBand) { cls = 0; av = lo - (int)dp.m - dp.kerr_lo; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool mine = any && cls == q;
+            const uint32_t iw = wave_append(&s_my[q], mine);
+            if (mine) {
+                cs.listW[q][seg0 + iw] = r;
+                cs.winW[q][seg0 + iw] = q == 0 ? (uint32_t)(av + kBandBias) : ((uint32_t)a1 | ((uint32_t)cl.jmax1 << 16));
+                if (q == 3) cs.winW2[seg0 + iw] = (uint32_t)a2 | ((uint32_t)cl.jmax2 << 16);
+            }
+        }
+        const bool toF = any && cls == 4;
+        const uint32_t jf = wave_append(&s_my[4], toF);
+        if (toF) cs.listF[seg0 + jf] = r;
+    }
+}
+
+// k_bmfilter: block filter and Myers pass of ONE adapter in one launch: a workgroup takes a
+// task segment through the block filter, then its rest through the Myers filter -- one launch and one tail per adapter
+// instead of two, the rest list never leaves the workgroup.
+template <int W, int NB>
+__global__ __launch_bounds__(kBlock) void k_bmfilter(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, DpParams dp,
+                                                     short2 *__restrict__ spans, BatchLists bl, uint64_t *__restrict__ counters) {
+    __shared__ uint32_t s_bf[3];
+    __shared__ uint32_t s_my[5];
+    __shared__ uint2 s_eq2[16];
+    __shared__ uint32_t s_row[(W + 2) * kBlock];
+    if (threadIdx.x < 16) s_eq2[threadIdx.x] = make_uint2(dp.eq_top[threadIdx.x & 3], dp.eq_top[threadIdx.x >> 2]);
+    const uint32_t *list = dp.is_prefix ? bl.listP : bl.listS;
+    const uint32_t *cnt = dp.is_prefix ? bl.cntP : bl.cntS;
+    ClassSet cs;
+    cs.listN = bl.listN; cs.winN = bl.winN; cs.winW2 = bl.winW2; cs.listF = bl.listF; cs.listR = bl.listR;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { cs.listW[q] = bl.listW[q]; cs.winW[q] = bl.winW[q]; }
+    uint32_t stat = 0;
+    for (uint32_t sb = blockIdx.x; sb < bl.grid; sb += gridDim.x) {
+        const uint32_t ntask = cnt[sb];
+        if (threadIdx.x < 3) s_bf[threadIdx.x] = 0;
+        if (threadIdx.x < 5) s_my[threadIdx.x] = 0;
+        __syncthreads();
+        const uint64_t seg0 = (uint64_t)sb * bl.seg;
+        if (ntask) front_bf_stage<W, NB>(rows, lens, dp, list, ntask, cs, seg0, s_bf, s_row + threadIdx.x);
+        __syncthreads();
+        const uint32_t nR = s_bf[2];
+        if (threadIdx.x == 0) s_my[0] = s_bf[1];
+        __syncthreads();
+        if (nR) front_myers_stage<W>(rows, lens, dp, spans, cs, nR, seg0, s_my, s_eq2);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            bl.cntN[sb] = s_bf[0]; bl.cntR[sb] = nR;
+            bl.cntW[0][sb] = s_my[0]; bl.cntW[1][sb] = s_my[1]; bl.cntW[2][sb] = s_my[2]; bl.cntW[3][sb] = s_my[3]; bl.cntF[sb] = s_my[4];
+            const uint32_t tb = dp.is_prefix ? 0u : 8u;
+            if (s_bf[0]) atomicAdd(&bl.tot[tb + 5u], s_bf[0]);
+            for (int q = 0; q < 5; ++q) if (s_my[q]) atomicAdd(&bl.tot[tb + (uint32_t)q], s_my[q]);
+        }
         stat += ntask;
         __syncthreads();
     }
@@ -778,20 +1070,20 @@ __device__ __forceinline__ void dpw_body(FlatList &fl, DpLds &L, const uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------
-// dp_banded: the same DP over a band of kBand diagonals (class 0 of the filter: every optimal alignment of the
-// task stays on diagonals j - i in [av, av + kBand)).  Relative column k = j - av runs from
-// 1 to M + kBand - 1 and holds the rows (k - kBand, k]: the code is fully unrolled over k, so the row a
-// register holds is static, a cell costs what it costs in dp_column and only M * kBand cells are computed
+// dp_banded<M, B>: the same DP over a band of B diagonals (B = kBand for class 0 of the Myers filter, kBandN for the narrow
+// class of the block filter: every optimal alignment of the task stays on diagonals j - i in [av, av + B)).
+// Relative column k = j - av runs from 1 to M + B - 1 and holds the rows (k - B, k]: the code is fully unrolled over k, so
+// the row a register holds is static, a cell costs what it costs in dp_column and only M * B cells are computed
 // instead of M * (m + kerr + spread).  Everything outside the band reads as -inf (entering row, row above
 // the band) or as the true boundary value (row 0; column 0 when the band starts left of the read, where
 // av < 0 stands for an adapter overhanging the read start): a value that is never above the true one and
 // exact on every cell of an optimal alignment, which is all the result depends on.  A lane is active
 // from its first real column (j >= 1) to its last (j <= n): per-column exec masks, no divergent loops.
 // ------------------------------------------------------------------------------------------------
-template <int M>
+template <int M, int B>
 __device__ __forceinline__ void dp_banded(const uint32_t *__restrict__ row, int W, int n, int av, const DpParams &dp, const DpLds &L,
                                           int &score, int &len) {
-    constexpr int KT = M + kBand - 1;
+    constexpr int KT = M + B - 1;
     int32_t H[M], E[M];
 #pragma unroll
     for (int i = 0; i < M; ++i) {                       // column 0 of the read (only read where it is the true boundary)
@@ -816,7 +1108,7 @@ __device__ __forceinline__ void dp_banded(const uint32_t *__restrict__ row, int 
 #pragma unroll
     for (int k = 1; k <= KT; ++k) {
         if (k >= k0 && k <= kend) {
-            const int r0 = k - kBand + 1 > 1 ? k - kBand + 1 : 1, r1 = k < M ? k : M;     // rows of this column, 1-based
+            const int r0 = k - B + 1 > 1 ? k - B + 1 : 1, r1 = k < M ? k : M;     // rows of this column, 1-based
             const uint32_t b = (Q[(k - 1) >> 4] >> (2 * ((k - 1) & 15))) & 3u;
             const int32_t *pc = L.prof + b * kProfStride;
             int32_t pv[M + 3];
@@ -859,12 +1151,13 @@ __device__ __forceinline__ void dp_banded(const uint32_t *__restrict__ row, int 
     }
 }
 
-template <int M>
+template <int M, int B>
 __device__ __forceinline__ void dpb_body(FlatList &fl, DpLds &L, const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
-                                         const DpParams &dp, short2 *__restrict__ spans, const BatchLists &bl, uint32_t bid, uint32_t nb) {
+                                         const DpParams &dp, short2 *__restrict__ spans, const BatchLists &bl,
+                                         const uint32_t *__restrict__ list, const uint32_t *__restrict__ win, const uint32_t *__restrict__ cnt,
+                                         uint32_t bid, uint32_t nb) {
     dp_lds_fill(L, dp);
-    const uint32_t *list = bl.listW[0], *win = bl.winW[0];
-    flat_build(fl, bl.cntW[0], bl.grid);
+    flat_build(fl, cnt, bl.grid);
     const uint32_t total = fl.pre[kMaxGrid];
     const uint32_t n_round = (total + WAVE - 1) / WAVE * WAVE;
     for (uint32_t t = bid * kBlock + threadIdx.x; t < n_round; t += nb * kBlock) {
@@ -879,7 +1172,7 @@ __device__ __forceinline__ void dpb_body(FlatList &fl, DpLds &L, const uint32_t 
             av = (int)win[at] - kBandBias;
         }
         int score, len;
-        dp_banded<M>(rows + (uint64_t)r * W, W, n, av, dp, L, score, len);
+        dp_banded<M, B>(rows + (uint64_t)r * W, W, n, av, dp, L, score, len);
         const bool pushS = dp_commit(valid, r, n, score >= dp.T, len, dp, spans);
         if (dp.is_prefix) push_suffix(bl, seg, r, pushS);
     }
@@ -902,31 +1195,32 @@ __global__ __launch_bounds__(kBlock) void k_dpall(const uint32_t *__restrict__ r
     const uint32_t *tot = bl.tot + (dp.is_prefix ? 0u : 8u);
     // relative cost of a task: banded M x kBand cells; one window ~ M x (m + kerr + 8); long / two windows ~ M x 64 x 1..2;
     // full width M x read length
-    const uint32_t cost[5] = {2u, 8u, 16u, 24u, 64u};
-    uint32_t nbk[5], t5[5];
+    // index 5 = the narrow band of the block filter (M x kBandN cells)
+    const uint32_t cost[6] = {4u, 16u, 32u, 48u, 128u, 2u};
+    uint32_t nbk[6], t5[6];
     uint64_t wsum = 0;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) { t5[q] = __builtin_amdgcn_readfirstlane(tot[q]); wsum += (uint64_t)t5[q] * cost[q]; }
+    for (int q = 0; q < 6; ++q) { t5[q] = __builtin_amdgcn_readfirstlane(tot[q]); wsum += (uint64_t)t5[q] * cost[q]; }
     if (wsum == 0) return;
     const uint32_t G = gridDim.x;
     uint32_t used = 0;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
+    for (int q = 0; q < 6; ++q) {
         uint32_t b = t5[q] ? (uint32_t)((uint64_t)G * t5[q] * cost[q] / wsum) : 0u;
         const uint32_t cap = (t5[q] + kBlock - 1) / kBlock;              // one workgroup per 256 tasks at most
         if (t5[q] && b < 1) b = 1;
-        if (q > 0 && cap <= 2 * b + 8) b = cap;                            // a small class runs as one trip: its latency is the launch's tail
+        if (q > 0 && q < 5 && cap <= 2 * b + 8) b = cap;                   // a small class runs as one trip: its latency is the launch's tail
         if (b > cap) b = cap;
         nbk[q] = b;
         used += b;
     }
     // the minimum of one block and the single-trip raise can exceed the grid: the largest classes pay (a class keeps one block)
 #pragma unroll
-    for (int it = 0; it < 5; ++it) {
+    for (int it = 0; it < 6; ++it) {
         if (used > G) {
             int big = 0;
 #pragma unroll
-            for (int q = 1; q < 5; ++q) if (nbk[q] > nbk[big]) big = q;
+            for (int q = 1; q < 6; ++q) if (nbk[q] > nbk[big]) big = q;
             const uint32_t cut = min(used - G, nbk[big] - 1u);
             nbk[big] -= cut;
             used -= cut;
@@ -934,7 +1228,9 @@ __global__ __launch_bounds__(kBlock) void k_dpall(const uint32_t *__restrict__ r
     }
     uint32_t b0 = 0;
     const uint32_t b = blockIdx.x;
-    if (b < b0 + nbk[0]) { dpb_body<M>(fl, L, rows, lens, W, dp, spans, bl, b - b0, nbk[0]); return; }
+    if (b < b0 + nbk[5]) { dpb_body<M, kBandN>(fl, L, rows, lens, W, dp, spans, bl, bl.listN, bl.winN, bl.cntN, b - b0, nbk[5]); return; }
+    b0 += nbk[5];
+    if (b < b0 + nbk[0]) { dpb_body<M, kBand>(fl, L, rows, lens, W, dp, spans, bl, bl.listW[0], bl.winW[0], bl.cntW[0], b - b0, nbk[0]); return; }
     b0 += nbk[0];
     if (b < b0 + nbk[1]) { dpw_body<M, false>(fl, L, rows, lens, W, dp, spans, bl, 1, b - b0, nbk[1]); return; }
     b0 += nbk[1];
@@ -2071,6 +2367,30 @@ hipError_t launch_filter(hipStream_t s, int W, const uint32_t *rows, const uint1
     }
     return hipGetLastError();
 }
+
+template <int W>
+static void launch_bmfilter_w(hipStream_t s, int g, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans, BatchLists bl,
+                              uint64_t *counters) {
+    switch (dp.nblk) {
+    case 2: hipLaunchKernelGGL((k_bmfilter<W, 2>), dim3(g), dim3(kBlock), 0, s, rows, lens, dp, spans, bl, counters); break;
+    case 3: hipLaunchKernelGGL((k_bmfilter<W, 3>), dim3(g), dim3(kBlock), 0, s, rows, lens, dp, spans, bl, counters); break;
+    default: hipLaunchKernelGGL((k_bmfilter<W, 4>), dim3(g), dim3(kBlock), 0, s, rows, lens, dp, spans, bl, counters); break;
+    }
+}
+hipError_t launch_bmfilter(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans, BatchLists bl,
+                           uint64_t *counters) {
+    if (bl.grid == 0) return hipSuccess;
+    if (dp.nblk < 2 || dp.nblk > 4) return hipErrorInvalidValue;
+    const int g = (int)bl.grid;
+    switch (W) {
+    case 10: launch_bmfilter_w<10>(s, g, rows, lens, dp, spans, bl, counters); break;
+    case 20: launch_bmfilter_w<20>(s, g, rows, lens, dp, spans, bl, counters); break;
+    case 40: launch_bmfilter_w<40>(s, g, rows, lens, dp, spans, bl, counters); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 
 hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n, const short2 *spans,
                          bool skip_translation, Table t) {
