@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--table-slots", type=int, default=0, help="count-table slots (0 = 2x the variant library, power of two)")
+    ap.add_argument("--merge-transport", default="auto", choices=["auto", "rccl", "torch"],
+                    help="final table reduce: rccl = the library's own exchange (vf_comm_init / vf_table_allreduce), torch = the same "
+                         "algorithm with torch.distributed moving the bytes; auto = rccl when the backend is nccl")
     ap.add_argument("--lib", default=None, help=argparse.SUPPRESS)      # diagnosis: another build of the library (make ablation)
     ap.add_argument("--dry-run", action="store_true", help="launcher / rank plumbing only (no device work): what the CPU test of --gpus N runs")
     args = ap.parse_args()
@@ -250,7 +253,7 @@ def main():
                 dist.all_reduce(tot)
                 barrier()
                 tm = time.perf_counter()
-                eng.allreduce_table(dst=0)
+                eng.allreduce_table(dst=0, transport=args.merge_transport)
                 torch.cuda.synchronize(dev)
                 barrier()
                 box["ms"] = (time.perf_counter() - tm) * 1e3
@@ -334,6 +337,7 @@ def main():
             "cpu_baseline": cpu,
             "parity_gate": parity, "parity_full_size": parity_full, "table_cleared_each_step": not keep_table,
             "merge_ms": None if merge_ms is None else round(merge_ms, 3), "merge_error": merge_error,
+            "merge_transport": None if world == 1 else (("rccl (vf_table_allreduce)" if args.backend == "nccl" else "torch") if args.merge_transport == "auto" else args.merge_transport),
             "per_step": {"dp_prefix_tasks": st["dp_prefix"] // steps, "dp_suffix_tasks": st["dp_suffix"] // steps, "insert_path_reads": st["insert_path"] // steps,
                          "accepted": st["accepted"] // steps, "counted": st["counted"] // steps,
                          "table_entries": st["table_entries"]},

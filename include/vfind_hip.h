@@ -81,6 +81,8 @@ typedef struct vf_stats {
     uint64_t launches_scan, launches_filter, launches_dp_window, launches_dp_rest, launches_finish, launches_generic;
     uint64_t insert_path;      /* counted reads whose one-shot table lookup missed (new, displaced or racing keys) */
     uint64_t arena_top;        /* dwords of the long-key arena handed out so far (keys longer than 56 bytes live there) */
+    double ms_result_build;    /* wall time of the latest vf_finish: table export, device dedupe + sort, copy of the frame */
+    uint64_t result_rows;      /* rows of that frame */
 } vf_stats;
 
 const char *vf_last_error(void);
@@ -123,6 +125,10 @@ int vf_sync(vf_ctx *ctx);
 /* Replaces the DataFrame build (lib.rs:312-319): the (sequence, count) table, rows sorted by
  * count descending then sequence ascending (the reference's order is unspecified). */
 int vf_finish(vf_ctx *ctx, vf_result **out);
+/* The same frame from several exported tables at once (vf_table_export / vf_table_partition_export blobs in this GPU's
+ * memory, e.g. the tables of all GPUs gathered here): equal strings are summed by the device result build, nothing is
+ * merged into this context's count table. */
+int vf_finish_blobs(vf_ctx *ctx, const void *const *d_blobs, const uint64_t *nbytes, uint32_t n_blobs, vf_result **out);
 uint64_t vf_result_rows(const vf_result *r);
 const uint8_t *vf_result_key_bytes(const vf_result *r);   /* concatenated UTF-8 keys  */
 const uint64_t *vf_result_key_offsets(const vf_result *r); /* rows+1 offsets           */
@@ -158,7 +164,22 @@ int vf_table_clear(vf_ctx *ctx);
  * peer's exported table (device memory, e.g. an RCCL receive buffer) into this GPU's table. */
 int vf_table_export_size(vf_ctx *ctx, uint64_t *nbytes);
 int vf_table_export(vf_ctx *ctx, void *d_dst, uint64_t capacity, uint64_t *written);
-int vf_table_merge(vf_ctx *ctx, const void *d_blob, uint64_t nbytes);
+int vf_table_merge(vf_ctx *ctx, const void *d_blob, uint64_t nbytes);   /* makes room first (grows the table / key arena) */
+
+/* Owner-partitioned exchange: every key has one owner among `world` GPUs (a function of its hash).  partition_sizes gives
+ * the byte size of each owner's share of this GPU's table (world values), partition_export writes one share in the format
+ * of vf_table_export.  A host with its own transport sends share o to GPU o, lets every owner clear its table and merge
+ * the shares it holds, and gathers the owners' tables (disjoint key sets) wherever it wants the sum. */
+int vf_table_partition_sizes(vf_ctx *ctx, uint32_t world, uint64_t *nbytes);
+int vf_table_partition_export(vf_ctx *ctx, uint32_t world, uint32_t owner, void *d_dst, uint64_t capacity, uint64_t *written);
+
+/* The same exchange over RCCL (xGMI inside a node), one context per process and GPU: rank 0 draws a 128-byte unique id and
+ * hands it to the other ranks by any means the host has; every rank calls vf_comm_init, and later vf_table_allreduce,
+ * after which rank `root` holds the sum of all ranks' tables (the other ranks keep their own share).  librccl.so.1 is
+ * loaded on first use. */
+int vf_comm_unique_id(void *id128);
+int vf_comm_init(vf_ctx *ctx, int rank, int world, const void *id128);
+int vf_table_allreduce(vf_ctx *ctx, int root);
 
 int vf_stats_get(vf_ctx *ctx, vf_stats *out);
 int vf_stats_reset(vf_ctx *ctx);

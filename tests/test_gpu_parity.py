@@ -722,3 +722,85 @@ def test_baseline_config_shapes_million_reads(name, kw, n):
         st = e.stats()
     assert got == want and len(got) > 5000
     assert st["dp_prefix"] > (500_000 if name == "cfg4" else 50_000)
+
+
+def test_owner_partitioned_exchange_between_local_contexts():
+    """the multi-GPU reduce as the library offers it without a transport of its own: every context buckets its entries by
+    owner (vf_table_partition_sizes / _export), bucket o goes to context o, every owner clears and merges what it holds,
+    the owners' shares are gathered at the root -- three contexts on one GPU, loop-back transport (device memory)"""
+    import torch
+    from vfind_amd import Engine
+    from vfind_amd.dist import allreduce_local
+    parts = [synth.make_reads(500 + k, 12000, AD20, L=150, n_variants=4000, sub=0.01) for k in range(3)]
+    engines = [Engine(AD20, table_slots=1 << (10 + 2 * k), arena_bytes=1 << 22) for k in range(3)]
+    try:
+        for e, p in zip(engines, parts):
+            e.submit(p)
+        # the shares of one table are disjoint and complete: their frames add up to the table's own frame
+        sizes = engines[1].partition_sizes(3)
+        assert len(sizes) == 3 and all(s >= 16 for s in sizes)
+        shares = []
+        for o in range(3):
+            buf = torch.zeros(sizes[o] + 64, dtype=torch.uint8, device="cuda")
+            assert engines[1].partition_export(3, o, buf.data_ptr(), buf.numel()) == sizes[o]
+            shares.append((buf, sizes[o]))
+        own = engines[1].finish_dict()
+        per_share = [engines[1].finish_blobs_dict([(b.data_ptr(), n)]) for b, n in shares]
+        assert sum(len(d) for d in per_share) == len(own) and min(len(d) for d in per_share) > len(own) // 6
+        merged = {}
+        for d in per_share:
+            assert not (merged.keys() & d.keys())
+            merged.update(d)
+        assert merged == own == oracle.count(parts[1], AD20)
+        allreduce_local(engines, root=0)
+        got = engines[0].finish_dict()
+        rest = [e.finish_dict() for e in engines[1:]]
+    finally:
+        for e in engines:
+            e.close()
+    want = oracle.count([r for p in parts for r in p], AD20)
+    assert got == want and len(got) > 5000
+    # the other contexts are left with their own share of the sum
+    for d in rest:
+        assert 0 < len(d) < len(want) and all(want[k] == v for k, v in d.items())
+
+
+def test_frame_from_several_exported_tables_sums_equal_strings():
+    """vf_finish_blobs: the tables of several contexts (overlapping key sets, translated and untranslated, long keys) laid end
+    to end and summed by the device result build -- same rows, counts and order as one context that saw all the reads"""
+    import torch
+    from vfind_amd import Engine
+    a = synth.make_reads(510, 9000, AD20, L=150, n_variants=1500, dirty=0.02)
+    b = synth.make_reads(510, 7000, AD20, L=150, n_variants=1500, dirty=0.02)[::-1]      # the same library: mostly shared keys
+    c = synth.make_reads(511, 2000, AD20, L=600, n_variants=300)                          # keys longer than 56 bytes
+    for kw in (dict(), dict(skip_translation=True)):
+        blobs, keep = [], []
+        with Engine(AD20, table_slots=1 << 13, **kw) as e1, Engine(AD20, table_slots=1 << 15, **kw) as e2, Engine(AD20, table_slots=1 << 12, **kw) as e3:
+            for e, reads in ((e1, a), (e2, b), (e3, c)):
+                e.submit(reads)
+                n = e.export_size()
+                buf = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+                e.export_to(buf.data_ptr(), buf.numel())
+                keep.append(buf)
+                blobs.append((buf.data_ptr(), n))
+            got = e1.finish_blobs_dict(blobs + [blobs[0]])                                  # the first table twice
+            assert e1.finish_dict() == oracle.count(a, AD20, **kw)                         # e1's own table is untouched
+        want = oracle.count(a + a + b + c, AD20, **kw)
+        assert got == want and len(got) > 1000
+
+
+def test_rccl_entry_points_single_rank():
+    """vf_comm_unique_id / vf_comm_init / vf_table_allreduce through the C ABI with a communicator of one rank (RCCL refuses
+    two ranks on one GPU, so more cannot run on this box): the library loads librccl, creates and destroys a communicator,
+    and the reduce of a one-rank world leaves the table as it is"""
+    from vfind_amd import Engine
+    reads = synth.make_reads(520, 5000, AD20, L=150, n_variants=500)
+    with Engine(AD20, table_slots=1 << 12) as e:
+        e.submit(reads)
+        uid = Engine.comm_unique_id()
+        assert len(uid) == 128 and any(uid)
+        e.comm_init(0, 1, uid)
+        e.allreduce_rccl(0)
+        assert e.finish_dict() == oracle.count(reads, AD20)
+        with pytest.raises(ValueError):
+            e.comm_init(2, 2, uid)

@@ -140,6 +140,31 @@ class Engine:
             self._L.vf_result_free(res)
         return keys, offs, cnts
 
+    def finish_blobs_dict(self, blobs) -> dict:
+        """{key: count} of several exported tables [(device pointer, nbytes), ...] summed by the device result build"""
+        n = len(blobs)
+        ptrs = (C.c_void_p * n)(*[b[0] for b in blobs])
+        sizes = (C.c_uint64 * n)(*[b[1] for b in blobs])
+        res = C.c_void_p()
+        check(self._L.vf_finish_blobs(self._ctx, ptrs, sizes, n, C.byref(res)))
+        try:
+            rows = self._L.vf_result_rows(res)
+            offs = np.ctypeslib.as_array(C.cast(self._L.vf_result_key_offsets(res), C.POINTER(C.c_uint64)), (rows + 1,)).copy()
+            cnts = np.ctypeslib.as_array(C.cast(self._L.vf_result_counts(res), C.POINTER(C.c_uint64)), (rows,)).copy() if rows else np.zeros(0, np.uint64)
+            nb = int(offs[-1])
+            raw = np.ctypeslib.as_array(C.cast(self._L.vf_result_key_bytes(res), C.POINTER(C.c_uint8)), (nb,)).tobytes() if nb else b""
+        finally:
+            self._L.vf_result_free(res)
+        out = {}
+        order = []
+        for i in range(rows):
+            k = raw[int(offs[i]):int(offs[i + 1])]
+            assert k not in out, "the device result build left a duplicate row"
+            out[k] = int(cnts[i])
+            order.append((k, int(cnts[i])))
+        assert order == sorted(order, key=lambda kv: (-kv[1], kv[0])), "rows are not ordered by count desc, sequence asc"
+        return out
+
     def finish_dict(self) -> dict:
         keys, offs, cnts = self.finish_arrays()
         raw = keys.tobytes()
@@ -192,35 +217,68 @@ class Engine:
     def merge_from(self, src_ptr: int, nbytes: int):
         check(self._L.vf_table_merge(self._ctx, src_ptr, nbytes))
 
-    def allreduce_table(self, group=None, dst: Optional[int] = 0):
-        """Sum the (key,count) tables of all ranks over RCCL (torch.distributed, backend nccl).
+    def partition_sizes(self, world: int):
+        """byte size of every owner's share of this table in an exchange between `world` GPUs"""
+        out = (C.c_uint64 * world)()
+        check(self._L.vf_table_partition_sizes(self._ctx, world, out))
+        return [int(x) for x in out]
 
-        Every rank exports its compacted table into a torch uint8 CUDA tensor, the tables are
-        all-gathered (padded to the largest), and rank `dst` (or every rank when dst is None)
-        merges its peers' tables on the device.  Returns merge time in seconds on merging ranks.
+    def partition_export(self, world: int, owner: int, dst_ptr: int, capacity: int) -> int:
+        w = C.c_uint64()
+        check(self._L.vf_table_partition_export(self._ctx, world, owner, dst_ptr, capacity, C.byref(w)))
+        return int(w.value)
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128-byte RCCL unique id (rank 0 draws it, the host shares it with the other ranks)"""
+        buf = C.create_string_buffer(128)
+        check(_lib.lib().vf_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be 128 bytes")
+        check(self._L.vf_comm_init(self._ctx, int(rank), int(world), unique_id))
+
+    def allreduce_rccl(self, root: int = 0):
+        """owner-partitioned reduce of all ranks' tables over RCCL, inside the library (vf_table_allreduce)"""
+        check(self._L.vf_table_allreduce(self._ctx, int(root)))
+
+    def allreduce_table(self, group=None, dst: int = 0, transport: str = "auto"):
+        """Sum the (key,count) tables of all ranks of a torch.distributed group at rank `dst`.
+
+        transport "rccl": the library's own exchange over RCCL (vf_comm_init / vf_table_allreduce through the C ABI; the
+        128-byte unique id travels through one torch broadcast).  "torch": the same owner-partitioned algorithm with
+        torch.distributed moving the bytes (what a CPU-side rehearsal over gloo uses).  "auto": rccl when the group's
+        backend is nccl, torch otherwise.  Returns the seconds the exchange took on this rank.
         """
         import time
 
         import torch
         import torch.distributed as dist
 
-        from .dist import allgather_blobs
+        from .dist import exchange_shares
 
         world = dist.get_world_size(group)
         rank = dist.get_rank(group)
         if world == 1:
             return 0.0
+        if transport == "auto":
+            transport = "rccl" if dist.get_backend(group) == "nccl" else "torch"
         dev = torch.device("cuda", self.device)
-        mine = self.export_size()
-        send = torch.zeros((mine + 255) // 256 * 256, dtype=torch.uint8, device=dev)
-        self.export_to(send.data_ptr(), send.numel())
-        parts = allgather_blobs(send, mine, group)
-        torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        if dst is None or rank == dst:
-            for r, (buf, nbytes) in enumerate(parts):
-                if r != rank:
-                    self.merge_from(buf.data_ptr(), nbytes)
+        if transport == "rccl":
+            if not getattr(self, "_comm_ready", False):
+                uid = torch.zeros(128, dtype=torch.uint8, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(self.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(uid, src=0, group=group)
+                self.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+                self._comm_ready = True
+            self.allreduce_rccl(dst)
+        else:
+            exchange_shares(self, group, dst)
+        torch.cuda.synchronize(dev)
         return time.perf_counter() - t0
 
     # ---- stats ----------------------------------------------------------------------------------

@@ -35,7 +35,7 @@ class VfStats(C.Structure):
         "reads", "reads_generic", "dp_prefix", "dp_suffix", "accepted", "counted", "table_entries", "arena_dwords")] + [
         (n, C.c_double) for n in ("ms_scan", "ms_filter", "ms_dp_window", "ms_dp_rest", "ms_finish", "ms_generic")] + [
         (n, C.c_uint64) for n in ("launches_scan", "launches_filter", "launches_dp_window", "launches_dp_rest", "launches_finish", "launches_generic",
-                                  "insert_path", "arena_top")]
+                                  "insert_path", "arena_top")] + [("ms_result_build", C.c_double), ("result_rows", C.c_uint64)]
 
 
 # every symbol include/vfind_hip.h declares: (name, restype, argtypes)
@@ -52,6 +52,7 @@ SYMBOLS = [
     ("vf_spans_ascii", C.c_int, [_P, _P, _P, C.c_uint64, _P, _P]),
     ("vf_sync", C.c_int, [_P]),
     ("vf_finish", C.c_int, [_P, C.POINTER(_P)]),
+    ("vf_finish_blobs", C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(_P)]),
     ("vf_result_rows", C.c_uint64, [_P]),
     ("vf_result_key_bytes", _P, [_P]),
     ("vf_result_key_offsets", _P, [_P]),
@@ -62,6 +63,11 @@ SYMBOLS = [
     ("vf_table_export_size", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("vf_table_export", C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("vf_table_merge", C.c_int, [_P, _P, C.c_uint64]),
+    ("vf_table_partition_sizes", C.c_int, [_P, C.c_uint32, _P]),
+    ("vf_table_partition_export", C.c_int, [_P, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("vf_comm_unique_id", C.c_int, [_P]),
+    ("vf_comm_init", C.c_int, [_P, C.c_int, C.c_int, _P]),
+    ("vf_table_allreduce", C.c_int, [_P, C.c_int]),
     ("vf_stats_get", C.c_int, [_P, C.POINTER(VfStats)]),
     ("vf_stats_reset", C.c_int, [_P]),
     ("vf_set_profiling", C.c_int, [_P, C.c_int]),

@@ -145,7 +145,9 @@ hipError_t launch_frame_pack(hipStream_t s, int W, const uint8_t *text, const ui
                              uint16_t *lens, uint32_t *gen_start, uint32_t *gen_len, uint32_t *info, bool all_generic);
 struct ClearRegions { void *p[4]; uint64_t bytes[4]; };   // 16-byte aligned starts, sizes multiples of 4
 hipError_t launch_clear(hipStream_t s, const ClearRegions &cr);
-hipError_t launch_export(hipStream_t s, Table t, uint64_t *out_refs, uint64_t *out_counts, uint32_t *out_arena);
+// G = 0: the whole table; otherwise the entries owned by `owner` of G in the multi-GPU exchange
+hipError_t launch_export(hipStream_t s, Table t, uint64_t *out_refs, uint64_t *out_counts, uint32_t *out_arena, uint32_t G, uint32_t owner);
+hipError_t launch_owner_count(hipStream_t s, Table t, uint32_t G, uint64_t *out);      // out[2 G]: entries, key dwords per owner (zeroed by the caller)
 hipError_t launch_rehash(hipStream_t s, Table from, Table to);
 hipError_t launch_merge(hipStream_t s, Table t, const uint64_t *refs, const uint64_t *counts,
                         const uint32_t *arena, uint64_t n);

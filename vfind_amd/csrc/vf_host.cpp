@@ -8,7 +8,10 @@
 #include "../../include/vfind_hip.h"
 #include "vf_device.h"
 #include "vf_internal.h"
+#include "vf_result.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -25,7 +28,7 @@
 #include <shared_mutex>
 #include <string>
 #include <thread>
-#include <unordered_map>
+#include <chrono>
 #include <vector>
 
 using namespace vf;
@@ -177,11 +180,19 @@ struct vf_ctx {
     ResLane res[kMaxResLanes];   // vf_process_device_packed: batch k+1's scan/DP overlaps batch k's finish
     uint32_t n_res = 2, res_next = 0;
     DevBuf<uint64_t> exp_refs, exp_counts;
+    // multi-GPU exchange
+    DevBuf<uint64_t> d_part;            // k_owner_count output
+    uint64_t part[2 * 64] = {};         // entries, key dwords per owner of the latest partition_counts
+    uint32_t part_world = 0;            // 0 = stale (the table changed since)
+    void *comm = nullptr;               // ncclComm_t of vf_comm_init
+    int comm_rank = 0, comm_world = 1;
     // stats / profiling
     std::atomic<uint64_t> n_reads{0}, n_generic{0};
     int profiling = 0;                  // 0 off, 1 every kernel bracket, 2 the table kernel (k_finish) only
     std::mutex ev_mu;
     std::vector<EventPair> pending_events;
+    double ms_result = 0;               // wall time of the latest vf_finish (export + device result build + copy back)
+    uint64_t result_rows = 0;
     double ms[K_KINDS] = {};
     uint64_t launches[K_KINDS] = {};
     // async error from worker threads
@@ -286,6 +297,8 @@ static void fill_dp(DpParams &d, const std::string &ad, int64_t T, const vf_ctx 
     for (int q = 0; q < 4; ++q) d.eq_top[q] = up ? ((d.eq[q] << up) | ((1u << up) - 1u)) : d.eq[q];
     d.pv_init = up ? (0xFFFFFFFFu << up) : 0xFFFFFFFFu;
 }
+
+static void vf_comm_release(vf_ctx *c);
 
 // ------------------------------------------------------------------------------------------------
 // create / destroy
@@ -429,7 +442,8 @@ extern "C" void vf_ctx_destroy(vf_ctx *c) {
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
-    c->exp_refs.release(); c->exp_counts.release();
+    c->exp_refs.release(); c->exp_counts.release(); c->d_part.release();
+    vf_comm_release(c);
     c->t_slots.release(); c->t_counts.release(); c->t_arena.release(); c->t_counters.release(); c->t_chunks.release();
     c->d_adapters.release();
     if (c->clear_event) (void)hipEventDestroy(c->clear_event);
@@ -572,6 +586,7 @@ static int reserve_capacity(vf_ctx *c, CapacityTicket &t, uint64_t n, uint64_t a
 static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &ws, const uint32_t *d_rows, int W,
                       const uint16_t *d_lens, uint64_t n, short2 *d_spans, bool count, uint64_t *h_entries) {
     if (n == 0) return VF_OK;
+    if (count) c->part_world = 0;
     if (n > 0xFFFFFFF0ull) return fail(VF_EINVAL, "batch too large (max 2^32-16 reads per submission)");
     BatchLists bl{};
     bl.listP = ws.listP.p; bl.listS = ws.listS.p; bl.listF = ws.listF.p;
@@ -953,6 +968,7 @@ extern "C" int vf_table_clear(vf_ctx *c) {
         if (L.in_flight) HIP_TRY(hipStreamWaitEvent(c->main_stream, L.done, 0));
     std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
     { std::lock_guard<std::mutex> g(c->cap_mu); c->upper_entries = c->unenqueued; c->upper_arena = c->unenqueued_arena; }
+    c->part_world = 0;
     return table_clear_locked(c);
 }
 
@@ -969,26 +985,61 @@ extern "C" int vf_table_export_size(vf_ctx *c, uint64_t *nbytes) {
 }
 
 // blob = {u64 n, u64 arena_dwords, u64 refs[n], u64 counts[n], u32 arena[arena_dwords]}
-extern "C" int vf_table_export(vf_ctx *c, void *d_dst, uint64_t capacity, uint64_t *written) {
-    if (!c || !d_dst) return fail(VF_EINVAL, "null argument");
-    int rc = vf_sync(c);
-    if (rc) return rc;
-    uint64_t h[C_NUM];
-    if ((rc = check_device_errors(c, h))) return rc;
-    const uint64_t n = h[C_ENTRIES], adw = h[C_KEY_DWORDS];
+// G = 0: the whole table (n, adw = its entry and key-dword counters); otherwise owner's share of G (n, adw from k_owner_count)
+static int export_blob(vf_ctx *c, uint32_t G, uint32_t owner, uint64_t n, uint64_t adw, void *d_dst, uint64_t capacity, uint64_t *written) {
     const uint64_t need = blob_bytes(n, adw);
     if (capacity < need) return fail(VF_EINVAL, "export buffer too small");
     uint8_t *dst = (uint8_t *)d_dst;
     const uint64_t hdr[2] = {n, adw};
     HIP_TRY(hipMemcpyAsync(dst, hdr, 16, hipMemcpyHostToDevice, c->main_stream));
     HIP_TRY(hipMemsetAsync(c->t_counters.p + C_EXPORT_N, 0, 2 * sizeof(uint64_t), c->main_stream));
-    HIP_TRY(launch_export(c->main_stream, c->tab, (uint64_t *)(dst + 16), (uint64_t *)(dst + 16 + n * 8), (uint32_t *)(dst + 16 + n * 16)));
+    HIP_TRY(launch_export(c->main_stream, c->tab, (uint64_t *)(dst + 16), (uint64_t *)(dst + 16 + n * 8), (uint32_t *)(dst + 16 + n * 16), G, owner));
     HIP_TRY(hipStreamSynchronize(c->main_stream));
     uint64_t got[2] = {0, 0};
     HIP_TRY(hipMemcpy(got, c->t_counters.p + C_EXPORT_N, 16, hipMemcpyDeviceToHost));
     if (got[0] != n || got[1] != adw) return fail(VF_EDEVICE, "table export count mismatch");
     if (written) *written = need;
     return VF_OK;
+}
+
+extern "C" int vf_table_export(vf_ctx *c, void *d_dst, uint64_t capacity, uint64_t *written) {
+    if (!c || !d_dst) return fail(VF_EINVAL, "null argument");
+    int rc = vf_sync(c);
+    if (rc) return rc;
+    uint64_t h[C_NUM];
+    if ((rc = check_device_errors(c, h))) return rc;
+    return export_blob(c, 0, 0, h[C_ENTRIES], h[C_KEY_DWORDS], d_dst, capacity, written);
+}
+
+// ---- owner-partitioned exchange: every key has one owner among the `world` GPUs ---------------------------
+// entries and key dwords of every owner's share of this GPU's table (cached in the context for the exports that follow)
+static int partition_counts(vf_ctx *c, uint32_t world) {
+    if (world == 0 || world > 64) return fail(VF_EINVAL, "world must be 1..64");
+    int rc = vf_sync(c);
+    if (rc) return rc;
+    if ((rc = check_device_errors(c, nullptr))) return rc;
+    if ((rc = c->d_part.ensure(2 * 64))) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_part.p, 0, 2 * 64 * sizeof(uint64_t), c->main_stream));
+    HIP_TRY(launch_owner_count(c->main_stream, c->tab, world, c->d_part.p));
+    HIP_TRY(hipMemcpyAsync(c->part, c->d_part.p, 2 * (size_t)world * sizeof(uint64_t), hipMemcpyDeviceToHost, c->main_stream));
+    HIP_TRY(hipStreamSynchronize(c->main_stream));
+    c->part_world = world;
+    return VF_OK;
+}
+extern "C" int vf_table_partition_sizes(vf_ctx *c, uint32_t world, uint64_t *nbytes) {
+    if (!c || !nbytes) return fail(VF_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->dev));
+    int rc = partition_counts(c, world);
+    if (rc) return rc;
+    for (uint32_t o = 0; o < world; ++o) nbytes[o] = blob_bytes(c->part[2 * o], c->part[2 * o + 1]);
+    return VF_OK;
+}
+extern "C" int vf_table_partition_export(vf_ctx *c, uint32_t world, uint32_t owner, void *d_dst, uint64_t capacity, uint64_t *written) {
+    if (!c || !d_dst) return fail(VF_EINVAL, "null argument");
+    if (world == 0 || owner >= world) return fail(VF_EINVAL, "owner out of range");
+    HIP_TRY(hipSetDevice(c->dev));
+    if (c->part_world != world) { int rc = partition_counts(c, world); if (rc) return rc; }
+    return export_blob(c, world, owner, c->part[2 * owner], c->part[2 * owner + 1], d_dst, capacity, written);
 }
 
 // header of an exported table as a peer sent it: checked without overflow before anything is sized from it
@@ -1019,6 +1070,7 @@ extern "C" int vf_table_merge(vf_ctx *c, const void *d_blob, uint64_t nbytes) {
         c->upper_entries += hdr[0]; c->upper_arena += hdr[1];
     }
     std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
+    c->part_world = 0;
     const uint8_t *b = (const uint8_t *)d_blob;
     HIP_TRY(launch_merge(c->main_stream, c->tab, (const uint64_t *)(b + 16), (const uint64_t *)(b + 16 + hdr[0] * 8),
                          (const uint32_t *)(b + 16 + hdr[0] * 16), hdr[0]));
@@ -1026,23 +1078,161 @@ extern "C" int vf_table_merge(vf_ctx *c, const void *d_blob, uint64_t nbytes) {
     return check_device_errors(c, nullptr);
 }
 
-static bool valid_utf8(const uint8_t *s, size_t n) {
-    size_t i = 0;
-    while (i < n) {
-        const uint8_t ch = s[i];
-        if (ch < 0x80) { ++i; continue; }
-        int len; uint32_t cp;
-        if ((ch & 0xE0) == 0xC0) { len = 2; cp = ch & 0x1F; }
-        else if ((ch & 0xF0) == 0xE0) { len = 3; cp = ch & 0x0F; }
-        else if ((ch & 0xF8) == 0xF0) { len = 4; cp = ch & 0x07; }
-        else return false;
-        if (i + len > n) return false;
-        for (int k = 1; k < len; ++k) { if ((s[i + k] & 0xC0) != 0x80) return false; cp = (cp << 6) | (s[i + k] & 0x3F); }
-        if ((len == 2 && cp < 0x80) || (len == 3 && cp < 0x800) || (len == 4 && (cp < 0x10000 || cp > 0x10FFFF))) return false;
-        if (cp >= 0xD800 && cp <= 0xDFFF) return false;
-        i += len;
+// ------------------------------------------------------------------------------------------------
+// RCCL (the multi-GPU reduce of the count table over xGMI).  librccl is loaded on first use: a host that runs one GPU
+// never needs it, and inside a process that already holds an RCCL (PyTorch ships one under the same soname) the loader
+// hands back that copy.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl *rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so"}) { r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
+        if (!r.h) return;
+        auto sym = [&](const char *n) { return dlsym(r.h, n); };
+        r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+        r.Send = (decltype(r.Send))sym("ncclSend");
+        r.Recv = (decltype(r.Recv))sym("ncclRecv");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.Send || !r.Recv || !r.GroupStart || !r.GroupEnd) r.h = nullptr;
+    });
+    return r.h ? &r : nullptr;
+}
+}  // namespace
+#define NCCL_TRY(expr)                                                                                     \
+    do {                                                                                                   \
+        ncclResult_t _r = (expr);                                                                          \
+        if (_r != ncclSuccess)                                                                             \
+            return fail(VF_EDEVICE, std::string(#expr) + ": " + (R->GetErrorString ? R->GetErrorString(_r) : "RCCL error")); \
+    } while (0)
+
+static void vf_comm_release(vf_ctx *c) {
+    if (c->comm) { if (Rccl *R = rccl()) (void)R->CommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
+    c->comm_rank = 0; c->comm_world = 1;
+}
+
+extern "C" int vf_comm_unique_id(void *id128) {
+    if (!id128) return fail(VF_EINVAL, "null argument");
+    Rccl *R = rccl();
+    if (!R) return fail(VF_EDEVICE, "librccl.so.1 is not loadable");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    NCCL_TRY(R->GetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return VF_OK;
+}
+
+extern "C" int vf_comm_init(vf_ctx *c, int rank, int world, const void *id128) {
+    if (!c || !id128) return fail(VF_EINVAL, "null argument");
+    if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(VF_EINVAL, "rank / world out of range (1..64 GPUs)");
+    Rccl *R = rccl();
+    if (!R) return fail(VF_EDEVICE, "librccl.so.1 is not loadable");
+    HIP_TRY(hipSetDevice(c->dev));
+    vf_comm_release(c);
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t comm = nullptr;
+    NCCL_TRY(R->CommInitRank(&comm, world, id, rank));
+    c->comm = comm; c->comm_rank = rank; c->comm_world = world;
+    return VF_OK;
+}
+
+// Owner-partitioned reduce of the count tables of all ranks (primary design):
+//   1. every rank buckets its entries by owner (hash tag -> one of `world`), sizes go round by ncclAllGather;
+//   2. ONE grouped ncclSend / ncclRecv exchange: bucket o of every rank to rank o (each entry crosses xGMI once, all
+//      links of a GPU busy at once, no ring);
+//   3. every owner empties its table and merges its own bucket and the world - 1 it received: its share, fully summed;
+//   4. the shares -- disjoint key sets -- go to `root` (sizes by ncclAllGather, one grouped exchange), which merges them.
+// Afterwards root's table is the sum of all tables; every other rank is left holding its own share.
+extern "C" int vf_table_allreduce(vf_ctx *c, int root) {
+    if (!c) return fail(VF_EINVAL, "null context");
+    const int G = c->comm_world, me = c->comm_rank;
+    if (G == 1) return VF_OK;
+    if (!c->comm) return fail(VF_EINVAL, "vf_comm_init has not been called");
+    if (root < 0 || root >= G) return fail(VF_EINVAL, "root out of range");
+    Rccl *R = rccl();
+    if (!R) return fail(VF_EDEVICE, "librccl.so.1 is not loadable");
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    HIP_TRY(hipSetDevice(c->dev));
+    hipStream_t st = c->main_stream;
+    int rc;
+    // 1. buckets
+    std::vector<uint64_t> mine(G), all((size_t)G * G);
+    if ((rc = vf_table_partition_sizes(c, (uint32_t)G, mine.data()))) return rc;
+    std::vector<uint64_t> soff(G + 1, 0);
+    for (int o = 0; o < G; ++o) soff[o + 1] = soff[o] + ((mine[o] + 255) & ~255ull);
+    DevBuf<uint8_t> sendbuf, recvbuf;
+    DevBuf<uint64_t> d_sizes;
+    struct Free { DevBuf<uint8_t> &a, &b; DevBuf<uint64_t> &c; ~Free() { a.release(); b.release(); c.release(); } } fr{sendbuf, recvbuf, d_sizes};
+    if ((rc = sendbuf.ensure(soff[G] + 256))) return rc;
+    for (int o = 0; o < G; ++o)
+        if ((rc = vf_table_partition_export(c, (uint32_t)G, (uint32_t)o, sendbuf.p + soff[o], mine[o], nullptr))) return rc;
+    if ((rc = d_sizes.ensure((size_t)G + (size_t)G * G))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_sizes.p, mine.data(), G * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    NCCL_TRY(R->AllGather(d_sizes.p, d_sizes.p + G, G, ncclUint64, comm, st));
+    HIP_TRY(hipMemcpyAsync(all.data(), d_sizes.p + G, (size_t)G * G * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    // 2. bucket `me` of every rank comes here
+    std::vector<uint64_t> roff(G + 1, 0);
+    for (int q = 0; q < G; ++q) roff[q + 1] = roff[q] + ((all[(size_t)q * G + me] + 255) & ~255ull);
+    if ((rc = recvbuf.ensure(roff[G] + 256))) return rc;
+    NCCL_TRY(R->GroupStart());
+    for (int p = 0; p < G; ++p) {
+        if (p == me) continue;
+        NCCL_TRY(R->Send(sendbuf.p + soff[p], mine[p], ncclUint8, p, comm, st));
+        NCCL_TRY(R->Recv(recvbuf.p + roff[p], all[(size_t)p * G + me], ncclUint8, p, comm, st));
     }
-    return true;
+    NCCL_TRY(R->GroupEnd());
+    HIP_TRY(hipStreamSynchronize(st));
+    // 3. this rank's share
+    if ((rc = vf_table_clear(c))) return rc;
+    if ((rc = vf_table_merge(c, sendbuf.p + soff[me], mine[me]))) return rc;
+    for (int q = 0; q < G; ++q)
+        if (q != me && (rc = vf_table_merge(c, recvbuf.p + roff[q], all[(size_t)q * G + me]))) return rc;
+    // 4. shares to root
+    uint64_t share = 0;
+    if ((rc = vf_table_export_size(c, &share))) return rc;
+    std::vector<uint64_t> shares(G);
+    HIP_TRY(hipMemcpyAsync(d_sizes.p, &share, sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    NCCL_TRY(R->AllGather(d_sizes.p, d_sizes.p + 1, 1, ncclUint64, comm, st));
+    HIP_TRY(hipMemcpyAsync(shares.data(), d_sizes.p + 1, G * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (me != root) {
+        if ((rc = sendbuf.ensure(share + 256))) return rc;
+        if ((rc = vf_table_export(c, sendbuf.p, share, nullptr))) return rc;
+        NCCL_TRY(R->Send(sendbuf.p, share, ncclUint8, root, comm, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return VF_OK;
+    }
+    std::vector<uint64_t> goff(G + 1, 0);
+    for (int q = 0; q < G; ++q) goff[q + 1] = goff[q] + (q == me ? 0 : ((shares[q] + 255) & ~255ull));
+    if ((rc = recvbuf.ensure(goff[G] + 256))) return rc;
+    NCCL_TRY(R->GroupStart());
+    for (int q = 0; q < G; ++q)
+        if (q != me) NCCL_TRY(R->Recv(recvbuf.p + goff[q], shares[q], ncclUint8, q, comm, st));
+    NCCL_TRY(R->GroupEnd());
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int q = 0; q < G; ++q)
+        if (q != me && (rc = vf_table_merge(c, recvbuf.p + goff[q], shares[q]))) return rc;
+    return VF_OK;
 }
 
 extern "C" int vf_finish(vf_ctx *c, vf_result **out) {
@@ -1054,51 +1244,63 @@ extern "C" int vf_finish(vf_ctx *c, vf_result **out) {
     DevBuf<uint8_t> blob;
     if ((rc = blob.ensure(nbytes))) return rc;
     struct Free { DevBuf<uint8_t> &b; ~Free() { b.release(); } } fr{blob};
+    const auto t0 = std::chrono::steady_clock::now();
     if ((rc = vf_table_export(c, blob.p, nbytes, nullptr))) return rc;
-    std::vector<uint8_t> h(nbytes);
-    HIP_TRY(hipMemcpy(h.data(), blob.p, nbytes, hipMemcpyDeviceToHost));
-    const uint64_t n = ((uint64_t *)h.data())[0];
-    const uint64_t *refs = (const uint64_t *)(h.data() + 16);
-    const uint64_t *cnts = refs + n;
-    const uint32_t *arena = (const uint32_t *)(h.data() + 16 + n * 16);
-    // the row set of the DataFrame (lib.rs:312-316); duplicate strings (possible only if the device
-    // saw a stale table word, see vf_kernels.hip:table_add) are summed here
-    std::unordered_map<std::string, uint64_t> rows;
-    rows.reserve(n * 2 + 1);
-    std::string key;
-    for (uint64_t i = 0; i < n; ++i) {
-        const uint64_t ref = refs[i];
-        const uint32_t len = (uint32_t)(ref & 0xFFFF), kind = (uint32_t)((ref >> 16) & 3);
-        const uint32_t *k = arena + (ref >> 24);
-        key.clear();
-        if (kind == kKindPacked) {
-            key.resize(len);
-            for (uint32_t b = 0; b < len; ++b) key[b] = "ACGT"[(k[b >> 4] >> (2 * (b & 15))) & 3u];
-        } else {
-            key.assign((const char *)k, len);
-            // String::from_utf8 guard of lib.rs:295 (peptides are ASCII by construction)
-            if (c->skip_translation && !valid_utf8((const uint8_t *)key.data(), key.size())) continue;
-        }
-        rows[key] += cnts[i];
-    }
-    std::vector<std::pair<const std::string *, uint64_t>> order;
-    order.reserve(rows.size());
-    for (auto &kv : rows) order.emplace_back(&kv.first, kv.second);
-    std::sort(order.begin(), order.end(), [](const auto &a, const auto &b) {
-        if (a.second != b.second) return a.second > b.second;
-        return *a.first < *b.first;
-    });
+    // the row set of the DataFrame (lib.rs:312-316) is built on the device (vf_result.hip): strings expanded, duplicate
+    // strings summed (possible only if the device saw a stale table word, see vf_kernels.hip:table_add), rows ordered by
+    // count descending then sequence ascending; only the three finished buffers come back
+    uint64_t hdr[2];
+    HIP_TRY(hipMemcpy(hdr, blob.p, 16, hipMemcpyDeviceToHost));
+    const uint64_t n = hdr[0];
     std::unique_ptr<vf_result> r(new vf_result);
-    r->offsets.reserve(order.size() + 1);
-    r->counts.reserve(order.size());
-    uint64_t top = 0;
-    for (auto &o : order) {
-        r->offsets.push_back(top);
-        r->keys.insert(r->keys.end(), o.first->begin(), o.first->end());
-        top += o.first->size();
-        r->counts.push_back(o.second);
+    std::string err;
+    rc = vf::build_result_on_device(c->main_stream, (const uint64_t *)(blob.p + 16), (const uint64_t *)(blob.p + 16 + n * 8),
+                                    (const uint32_t *)(blob.p + 16 + n * 16), n, c->skip_translation, *r, err);
+    if (rc) return fail(rc, err);
+    c->ms_result = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c->result_rows = r->counts.size();
+    *out = r.release();
+    return VF_OK;
+}
+
+// The frame of several exported tables at once (the tables of several GPUs gathered on one device, or the shares of an
+// owner-partitioned exchange): laid end to end and handed to the device result build, which sums equal strings -- no merge
+// into a count table in between.
+extern "C" int vf_finish_blobs(vf_ctx *c, const void *const *d_blobs, const uint64_t *nbytes, uint32_t n_blobs, vf_result **out) {
+    if (!c || !out || (n_blobs && (!d_blobs || !nbytes))) return fail(VF_EINVAL, "null argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(c->dev));
+    int rc;
+    std::vector<uint64_t> n(n_blobs), adw(n_blobs);
+    uint64_t tot_n = 0, tot_adw = 0;
+    for (uint32_t k = 0; k < n_blobs; ++k) {
+        if (!d_blobs[k] || nbytes[k] < 16) return fail(VF_EINVAL, "blob too small");
+        uint64_t hdr[2];
+        HIP_TRY(hipMemcpy(hdr, d_blobs[k], 16, hipMemcpyDeviceToHost));
+        if ((rc = blob_header_ok(hdr, nbytes[k]))) return rc;
+        n[k] = hdr[0]; adw[k] = hdr[1];
+        tot_n += hdr[0]; tot_adw += hdr[1];
     }
-    r->offsets.push_back(top);
+    if (tot_adw >> 39) return fail(VF_ECAPACITY, "gathered tables hold more key dwords than an entry reference can address");
+    const auto t0 = std::chrono::steady_clock::now();
+    DevBuf<uint64_t> refs, counts;
+    DevBuf<uint32_t> arena;
+    struct Free { DevBuf<uint64_t> &a, &b; DevBuf<uint32_t> &c; ~Free() { a.release(); b.release(); c.release(); } } fr{refs, counts, arena};
+    if ((rc = refs.ensure(tot_n)) || (rc = counts.ensure(tot_n)) || (rc = arena.ensure(tot_adw))) return rc;
+    uint64_t at_n = 0, at_adw = 0;
+    for (uint32_t k = 0; k < n_blobs; ++k) {
+        const uint8_t *b = (const uint8_t *)d_blobs[k];
+        HIP_TRY(vf::rebase_refs(c->main_stream, (const uint64_t *)(b + 16), n[k], at_adw, refs.p + at_n));
+        if (n[k]) HIP_TRY(hipMemcpyAsync(counts.p + at_n, b + 16 + n[k] * 8, n[k] * 8, hipMemcpyDeviceToDevice, c->main_stream));
+        if (adw[k]) HIP_TRY(hipMemcpyAsync(arena.p + at_adw, b + 16 + n[k] * 16, adw[k] * 4, hipMemcpyDeviceToDevice, c->main_stream));
+        at_n += n[k]; at_adw += adw[k];
+    }
+    std::unique_ptr<vf_result> r(new vf_result);
+    std::string err;
+    rc = vf::build_result_on_device(c->main_stream, refs.p, counts.p, arena.p, tot_n, c->skip_translation, *r, err);
+    if (rc) return fail(rc, err);
+    c->ms_result = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c->result_rows = r->counts.size();
     *out = r.release();
     return VF_OK;
 }
@@ -1125,6 +1327,7 @@ extern "C" int vf_stats_get(vf_ctx *c, vf_stats *o) {
     o->table_entries = h[C_ENTRIES]; o->arena_dwords = h[C_KEY_DWORDS]; o->arena_top = h[C_ARENA_TOP];
     o->ms_scan = c->ms[K_SCAN]; o->ms_filter = c->ms[K_FILTER]; o->ms_dp_window = c->ms[K_DPW]; o->ms_dp_rest = c->ms[K_DPREST];
     o->ms_finish = c->ms[K_FIN]; o->ms_generic = c->ms[K_GEN];
+    o->ms_result_build = c->ms_result; o->result_rows = c->result_rows;
     o->launches_scan = c->launches[K_SCAN]; o->launches_filter = c->launches[K_FILTER];
     o->launches_dp_window = c->launches[K_DPW]; o->launches_dp_rest = c->launches[K_DPREST];
     o->launches_finish = c->launches[K_FIN]; o->launches_generic = c->launches[K_GEN];

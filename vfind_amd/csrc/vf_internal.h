@@ -28,3 +28,4 @@ struct vf_result {
     std::vector<uint64_t> offsets;    // rows + 1
     std::vector<uint64_t> counts;     // rows
 };
+

@@ -2158,8 +2158,35 @@ __global__ __launch_bounds__(kBlock) void k_frame_pack(const uint8_t *__restrict
 // ------------------------------------------------------------------------------------------------
 // table export (compaction) and merge (multi-GPU exchange)
 // ------------------------------------------------------------------------------------------------
+// Owner of a key in the exchange between G GPUs (the multi-GPU reduce of lib.rs:292-306): a multiply-shift range
+// reduction of the key's 32-bit hash tag (the low word of w0), independent of the slot index and of the table's size.
+__device__ __forceinline__ uint32_t key_owner(uint64_t w0, uint32_t G) { return (uint32_t)(((uint64_t)(uint32_t)w0 * G) >> 32); }
+
+// entries and key dwords per owner: out[2 * o], out[2 * o + 1]   (G <= kMaxOwners)
+constexpr uint32_t kMaxOwners = 64;
+__global__ __launch_bounds__(kBlock) void k_owner_count(Table t, uint32_t G, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long s_h[2 * kMaxOwners];
+    for (uint32_t i = threadIdx.x; i < 2 * kMaxOwners; i += kBlock) s_h[i] = 0;
+    __syncthreads();
+    const uint64_t nslots = (uint64_t)t.slot_mask + 1;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t s = (uint64_t)blockIdx.x * kBlock + threadIdx.x; s < nslots; s += stride) {
+        const uint2 h = *reinterpret_cast<const uint2 *>(t.slots + s * 4);
+        const uint64_t w0 = (uint64_t)h.x | ((uint64_t)h.y << 32);
+        if ((w0 & kW0Ready) && !(w0 & kW0Ovf)) {
+            const uint32_t meta = (uint32_t)(w0 >> 32) & 0x3FFFFu;
+            const uint32_t o = key_owner(w0, G);
+            atomicAdd(&s_h[2 * o], 1ull);
+            atomicAdd(&s_h[2 * o + 1], (unsigned long long)key_dwords(meta >> 16, meta & 0xFFFFu));
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 2 * G; i += kBlock) if (s_h[i]) atomicAdd(&out[i], s_h[i]);
+}
+
+// G = 0: every live entry; otherwise only the entries whose key belongs to `owner` of G
 __global__ __launch_bounds__(kBlock) void k_export(Table t, uint64_t *__restrict__ out_refs, uint64_t *__restrict__ out_counts,
-                                                   uint32_t *__restrict__ out_arena) {
+                                                   uint32_t *__restrict__ out_arena, uint32_t G, uint32_t owner) {
     const uint64_t nslots = (uint64_t)t.slot_mask + 1;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t s0 = (uint64_t)blockIdx.x * kBlock; s0 < nslots; s0 += stride) {
@@ -2170,7 +2197,7 @@ __global__ __launch_bounds__(kBlock) void k_export(Table t, uint64_t *__restrict
             const uint4 *sp = t.slots + s * 4;
             l0 = sp[0];
             const uint64_t w0 = (uint64_t)l0.x | ((uint64_t)l0.y << 32);
-            live = (w0 & kW0Ready) && !(w0 & kW0Ovf);
+            live = (w0 & kW0Ready) && !(w0 & kW0Ovf) && (G == 0u || key_owner(w0, G) == owner);
             if (live) { l1 = sp[1]; l2 = sp[2]; l3 = sp[3]; }
         }
         const uint64_t m = __ballot(live);
@@ -2500,9 +2527,16 @@ hipError_t launch_clear(hipStream_t s, const ClearRegions &cr) {
     return hipGetLastError();
 }
 
-hipError_t launch_export(hipStream_t s, Table t, uint64_t *out_refs, uint64_t *out_counts, uint32_t *out_arena) {
+hipError_t launch_export(hipStream_t s, Table t, uint64_t *out_refs, uint64_t *out_counts, uint32_t *out_arena, uint32_t G, uint32_t owner) {
     const int g = grid_for((uint64_t)t.slot_mask + 1, 8);
-    hipLaunchKernelGGL(k_export, dim3(g), dim3(kBlock), 0, s, t, out_refs, out_counts, out_arena);
+    hipLaunchKernelGGL(k_export, dim3(g), dim3(kBlock), 0, s, t, out_refs, out_counts, out_arena, G, owner);
+    return hipGetLastError();
+}
+
+hipError_t launch_owner_count(hipStream_t s, Table t, uint32_t G, uint64_t *out) {
+    if (G == 0 || G > kMaxOwners) return hipErrorInvalidValue;
+    const int g = grid_for((uint64_t)t.slot_mask + 1, 8);
+    hipLaunchKernelGGL(k_owner_count, dim3(g), dim3(kBlock), 0, s, t, G, reinterpret_cast<unsigned long long *>(out));
     return hipGetLastError();
 }
 

@@ -42,3 +42,70 @@ def allgather_blobs(send, nbytes: int, group=None) -> List[Tuple[object, int]]:
     if via_host:
         recv = recv.to(send.device)
     return [(recv[r * cap:(r + 1) * cap], sizes_h[r]) for r in range(world)]
+
+
+def exchange_shares(engine, group=None, dst: int = 0):
+    """The owner-partitioned reduce of the count tables with torch.distributed as the transport: every rank
+    buckets its entries by owner (vf_table_partition_export), bucket o goes to rank o, every owner clears its table and
+    merges the buckets it holds, and the owners' tables (disjoint key sets) are gathered and merged at `dst`.
+    The bytes move through all_gather of padded blobs, which every backend offers (gloo in the CPU-side rehearsal)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = torch.device("cuda", engine.device)
+    sizes = engine.partition_sizes(world)
+    received = []
+    for owner in range(world):                                   # round o: everybody's bucket for owner o
+        send = torch.zeros((sizes[owner] + 255) // 256 * 256, dtype=torch.uint8, device=dev)
+        engine.partition_export(world, owner, send.data_ptr(), send.numel())
+        parts = allgather_blobs(send, sizes[owner], group)
+        if owner == rank:
+            received = parts
+    engine.clear()
+    for buf, nbytes in received:
+        engine.merge_from(buf.data_ptr(), nbytes)
+    mine = engine.export_size()
+    send = torch.zeros((mine + 255) // 256 * 256, dtype=torch.uint8, device=dev)
+    engine.export_to(send.data_ptr(), send.numel())
+    parts = allgather_blobs(send, mine, group)
+    if rank == dst:
+        for r, (buf, nbytes) in enumerate(parts):
+            if r != rank:
+                engine.merge_from(buf.data_ptr(), nbytes)
+
+
+def allreduce_local(engines, root: int = 0):
+    """The same exchange between contexts of ONE process (several GPUs driven by one host thread, or a one-GPU rehearsal
+    of the partition logic): bucket o of every context goes to context o by device memory, no collective involved."""
+    import torch
+
+    world = len(engines)
+    if world == 1:
+        return
+    buckets = []
+    for e in engines:
+        sizes = e.partition_sizes(world)
+        row = []
+        for owner in range(world):
+            buf = torch.zeros(max(sizes[owner], 16), dtype=torch.uint8, device=torch.device("cuda", e.device))
+            e.partition_export(world, owner, buf.data_ptr(), buf.numel())
+            row.append((buf, sizes[owner]))
+        buckets.append(row)
+    for o, e in enumerate(engines):
+        e.clear()
+        dev = torch.device("cuda", e.device)
+        for q in range(world):
+            buf, nbytes = buckets[q][o]
+            here = buf if buf.device == dev else buf.to(dev)        # kept alive across the (synchronous) merge
+            e.merge_from(here.data_ptr(), nbytes)
+    for o, e in enumerate(engines):
+        if o == root:
+            continue
+        n = e.export_size()
+        buf = torch.zeros(n + 64, dtype=torch.uint8, device=torch.device("cuda", e.device))
+        e.export_to(buf.data_ptr(), buf.numel())
+        rdev = torch.device("cuda", engines[root].device)
+        b2 = buf.to(rdev) if buf.device != rdev else buf
+        engines[root].merge_from(b2.data_ptr(), n)
