@@ -29,6 +29,92 @@ def b_alg(read_len: int) -> int:
     return (2 * read_len + 7) // 8 + 4
 
 
+def tie_sensitive_fraction(data, offs, ads, oracle, budget_s=8.0, max_reads=400):
+    """Among the probe's reads that needed an alignment and were accepted for that adapter: the fraction whose optimal
+    alignments do not all have the same `length` (so parasail's tie-breaking, which nothing pins, decides the cut)."""
+    from oracle import pyref
+    st, en = oracle.spans((data, offs), ads, n_threads=8)
+    t0 = time.perf_counter()
+    seen = tied = 0
+    raw = data.tobytes()
+    for i in range(len(offs) - 1):
+        if seen >= max_reads or time.perf_counter() - t0 > budget_s:
+            break
+        r = raw[int(offs[i]):int(offs[i + 1])]
+        for ad, coord in ((ads[0], st[i]), (ads[1], en[i])):
+            if coord < 0 or oracle.find_exact(r, ad) >= 0:
+                continue                                   # not accepted, or found exactly: no alignment involved
+            _, ends = pyref.cooptimal(ad.encode(), r)
+            seen += 1
+            tied += len({e[2] for e in ends}) > 1
+    return {"value": round(tied / seen, 4) if seen else None, "alignments_examined": seen, "tied": tied,
+            "what": "accepted alignments of the benchmark input whose co-optimal paths differ in length (oracle/pyref.py enumerator); "
+                    "kernel == oracle there under tie policy P, oracle == parasail is unpinned"}
+
+
+def pcie_inclusive_leg(vfind_amd, gen, ads, n, L, device, slots, host_threads, rounds=3, queue_len=4):
+    """reads/s with the batches in page-locked HOST memory when the clock starts: vf_batch_acquire / vf_batch_submit, queue_len
+    slots, hipMemcpyAsync of batch k + 1 overlapped with the kernels of batch k.  The staging is filled once (the host decoder's
+    own speed is not part of this leg) and re-submitted `rounds` times."""
+    nb = n // queue_len
+    eng = vfind_amd.Engine(ads, device=device, table_slots=slots, arena_bytes=1 << 30, queue_len=queue_len)
+    try:
+        W = gen.row_dwords
+        for k in range(queue_len):                       # fill every slot's staging once
+            h, r, l = eng.batch_acquire(nb, W)
+            gen.packed_into(k * nb, nb, r.ctypes.data, l.ctypes.data, host_threads)
+            eng.batch_submit(h, nb)
+        eng.sync()
+        eng.clear()
+        t0 = time.perf_counter()
+        for _ in range(rounds * queue_len):
+            h, r, l = eng.batch_acquire(nb, W)           # the oldest slot: its rows are still in the staging
+            eng.batch_submit(h, nb)
+        eng.sync()
+        dt = time.perf_counter() - t0
+        reads = rounds * queue_len * nb
+        row_b = W * 4 + 2
+        return {"value": round(reads / dt / 1e6, 2), "unit": "M reads/s", "link_GBps": round(reads * row_b / dt / 1e9, 2),
+                "link_peak_GBps": 63.0, "batches": rounds * queue_len, "reads_per_batch": nb, "queue_len": queue_len,
+                "what": "packed reads in the library's page-locked staging -> hipMemcpyAsync -> whole device path, table not cleared between batches"}
+    finally:
+        eng.close()
+
+
+def end_to_end_leg(vfind_amd, gen, ads, n_reads, device, slots):
+    """find_variants as a user calls it: gzip FASTQ file -> frame.  A multi-member file of the bench's own reads (level 1, binned
+    quality strings), timed with the reference's default n_threads = 3 and with all 16 threads of the box's share."""
+    import tempfile
+    from benchlib import fastq
+    out = {"reads": n_reads, "members": 32}
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "bench.fq.gz")
+        t0 = time.perf_counter()
+        out["file_MB"] = round(fastq.write_fastq_gz(path, gen, n_reads, members=32, threads=16) / 1e6, 1)
+        out["write_s"] = round(time.perf_counter() - t0, 1)
+        for nt in (3, 16):
+            with vfind_amd.Engine(ads, device=device, table_slots=slots, arena_bytes=1 << 30, n_threads=nt, queue_len=4) as e:
+                e.run_fastq(path)                          # first call allocates staging and workspaces
+                e.clear()
+                t0 = time.perf_counter()
+                e.run_fastq(path)
+                frame = e.finish_arrays()
+                dt = time.perf_counter() - t0
+                out[f"n_threads_{nt}"] = {"value": round(n_reads / dt / 1e6, 2), "unit": "M reads/s", "seconds": round(dt, 3), "rows": len(frame[2])}
+    out["what"] = "vf_run_fastq + vf_finish on a gzip FASTQ of the same read model (host inflate bound; never `value`)"
+    return out
+
+
+def valu_util_from_profiles():
+    """per-kernel VALU utilisation from the SQ counter pass committed under profiles/ (scripts/pmc_sq.sh)"""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sq.json")))
+        return {"source": "profiles/r02_pmc_sq.json", "definition": j.get("definition"),
+                "kernels": {k: v.get("valu_util") for k, v in j.get("kernels", {}).items()}}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -47,6 +133,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--table-slots", type=int, default=0, help="count-table slots (0 = 2x the variant library, power of two)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the legs beside the headline: result build, PCIe-inclusive, end-to-end FASTQ, tie-sensitive fraction")
+    ap.add_argument("--e2e-reads", type=int, default=2_000_000, help="reads of the gzip FASTQ file of the end-to-end leg")
     ap.add_argument("--merge-transport", default="auto", choices=["auto", "rccl", "torch"],
                     help="final table reduce: rccl = the library's own exchange (vf_comm_init / vf_table_allreduce), torch = the same "
                          "algorithm with torch.distributed moving the bytes; auto = rccl when the backend is nccl")
@@ -143,6 +231,7 @@ def main():
     # ---- parity gate (rank 0): device path == CPU oracle on a sample of the same reads -----------
     parity = None
     cpu = None
+    tie = None
     oracle_full, oracle_full_n = None, 0
     if world > 1:
         args.no_cpu_baseline = True       # the CPU baseline is timed at N=1 only (the other ranks would wait for it)
@@ -173,7 +262,8 @@ def main():
                 best = dt if best is None else min(best, dt)
             oracle_full_n = sample
             cpu = {"value": round(sample / best / 1e6, 4), "unit": "M reads/s", "cores": cores, "kind": "port",
-                   "sample": f"first {sample} reads of the same workload, all {cores} host threads, best of 2; "
+                   "sample": f"first {sample} reads of the same workload, all {cores} host threads, each with its own count table merged at "
+                             "the end (BASELINE.md 3 planned one serial reducer: this shape favours the CPU), best of 2 runs; "
                              "CPU restatement of vfind 0.3.1 (reference not buildable: no rustc/parasail)"}
             # the reference's default worker count (n_threads = 3, lib.rs:178) on a tenth of that sample
             s3 = max(probe_n, sample // 10)
@@ -181,6 +271,10 @@ def main():
             oracle.count((sb[: s3 * L], so[: s3 + 1]), ads, n_threads=3)
             cpu["at_reference_default_threads"] = {"value": round(s3 / max(time.perf_counter() - tq, 1e-4) / 1e6, 4), "cores": 3, "sample_reads": s3}
             del sb, so
+        # fraction of this input's accepted alignments whose `length` depends on the aligner's tie-breaking (BASELINE.md 4,
+        # SURVEY App. B.4): sampled with the exhaustive co-optimal enumerator of oracle/pyref.py on reads of the probe
+        if not args.no_extras and not args.no_parity:
+            tie = tie_sensitive_fraction(pb, po, ads, oracle, budget_s=8.0)
         del pb, po
     eng.reset_stats()
 
@@ -221,6 +315,18 @@ def main():
         if not parity_full:
             raise SystemExit("PARITY FAILED at full size: device table differs from the CPU oracle")
     oracle_full = None
+
+    # ---- beside the headline (rank 0 at N = 1; none of it is `value`) ---------------------------------------------
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras:
+        # the (sequence, count) frame of the last step's table: export, device dedupe + sort, one copy back
+        keys, offs, cnts = eng.finish_arrays()
+        fs = eng.stats()
+        extras["finish"] = {"ms": round(fs["ms_result_build"], 3), "rows": int(fs["result_rows"]), "key_bytes": int(offs[-1]) if len(offs) else 0,
+                            "what": "vf_finish: table export, strings expanded + duplicates summed + rows sorted (count desc, sequence asc) on the device, one copy back"}
+        del keys, offs, cnts
+        extras["pcie_inclusive"] = pcie_inclusive_leg(vfind_amd, gen, ads, n, L, local_rank, slots, host_threads)
+        extras["end_to_end"] = end_to_end_leg(vfind_amd, gen, ads, args.e2e_reads, local_rank, slots)
 
     # per-kernel durations of every kernel kind: the same steps again with all brackets on (not in `value`)
     if ev_mode == 2:
@@ -338,6 +444,8 @@ def main():
             "parity_gate": parity, "parity_full_size": parity_full, "table_cleared_each_step": not keep_table,
             "merge_ms": None if merge_ms is None else round(merge_ms, 3), "merge_error": merge_error,
             "merge_transport": None if world == 1 else (("rccl (vf_table_allreduce)" if args.backend == "nccl" else "torch") if args.merge_transport == "auto" else args.merge_transport),
+            "finish": extras.get("finish"), "pcie_inclusive": extras.get("pcie_inclusive"), "end_to_end": extras.get("end_to_end"),
+            "tie_sensitive_frac": tie, "valu_util": valu_util_from_profiles(),
             "per_step": {"dp_prefix_tasks": st["dp_prefix"] // steps, "dp_suffix_tasks": st["dp_suffix"] // steps, "insert_path_reads": st["insert_path"] // steps,
                          "accepted": st["accepted"] // steps, "counted": st["counted"] // steps,
                          "table_entries": st["table_entries"]},

@@ -90,6 +90,11 @@ class Generator:
         offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(self.read_len)
         return out, offs
 
+    def packed_into(self, first: int, n: int, rows_ptr: int, lens_ptr: int, threads: int = 8):
+        """the same into memory the caller owns (e.g. the library's page-locked batch staging): rows n * W uint32, lens n uint16"""
+        if self._L.vf_synth_generate(self._g, first, n, None, rows_ptr, self.row_dwords, lens_ptr, threads):
+            raise RuntimeError("synth failed")
+
     def packed(self, first: int, n: int, threads: int = 8):
         """-> (uint32 rows [n, W], uint16 lens [n])"""
         rows = np.empty((n, self.row_dwords), np.uint32)

@@ -109,6 +109,16 @@ int vf_submit_ascii(vf_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, 
 int vf_submit_packed(vf_ctx *ctx, const uint32_t *rows, uint32_t row_dwords, const uint16_t *lens,
                      uint64_t n_reads);
 
+/* Same without the staging copy: the caller packs straight into page-locked memory the library owns.  vf_batch_acquire
+ * hands out the staging of a free batch slot (it blocks while all queue_len slots are in flight): rows = n_reads *
+ * row_dwords dwords in the layout above, lens = n_reads lengths; vf_batch_submit enqueues the first n_reads of it
+ * (hipMemcpyAsync + kernels on the slot's own stream, overlapped with the other slots) and returns at once;
+ * vf_batch_release gives an acquired batch back unused.  The pointers are invalid after submit / release. */
+typedef struct vf_batch vf_batch;
+int vf_batch_acquire(vf_ctx *ctx, uint64_t n_reads, uint32_t row_dwords, vf_batch **batch, uint32_t **rows, uint16_t **lens);
+int vf_batch_submit(vf_ctx *ctx, vf_batch *batch, uint64_t n_reads);
+int vf_batch_release(vf_ctx *ctx, vf_batch *batch);
+
 /* Same for a packed batch already resident in HBM (the kernel-only benchmark path).  d_spans
  * may be NULL; otherwise it receives n_reads {int16 start, int16 end} pairs (-1 = None). */
 int vf_process_device_packed(vf_ctx *ctx, const void *d_rows, uint32_t row_dwords, const void *d_lens,

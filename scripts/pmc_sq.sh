@@ -2,6 +2,8 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${1:-r2_pmc_sq}
-VFIND_RES_LANES=1 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity > $OUT.log 2>&1
+VFIND_RES_LANES=1 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-extras > $OUT.log 2>&1
 f=$(find $OUT -name "*counter_collection.csv" | head -1)
 python3 $R/scripts/pmc_summary.py $f
+t=$(find $OUT -name "*kernel_trace.csv" | head -1)
+python3 $R/scripts/pmc_to_profiles.py $f $t $OUT.json

@@ -804,3 +804,35 @@ def test_rccl_entry_points_single_rank():
         assert e.finish_dict() == oracle.count(reads, AD20)
         with pytest.raises(ValueError):
             e.comm_init(2, 2, uid)
+
+
+def test_pinned_batch_api_round_trips_the_slots():
+    """vf_batch_acquire / vf_batch_submit: the caller packs straight into the library's page-locked staging; one thread walks
+    round the queue_len slots (acquire hands out the slot used longest ago), results equal the oracle, an acquired batch can be
+    given back unused, over-long reads and over-full submits are refused"""
+    from vfind_amd import Engine
+    from benchlib import synth as vsynth
+    ads = vsynth.adapters(77, 20)
+    gen = vsynth.Generator(77, ads, n_variants=3000)
+    n, nb = 40000, 5000
+    data, offs = gen.ascii(0, n, 4)
+    with Engine(ads, queue_len=3, table_slots=1 << 14) as e:
+        seen = set()
+        for k in range(n // nb):
+            h, rows, lens = e.batch_acquire(nb + 100, gen.row_dwords)        # room for more than is submitted
+            seen.add(rows.ctypes.data)
+            gen.packed_into(k * nb, nb, rows.ctypes.data, lens.ctypes.data, 2)
+            e.batch_submit(h, nb)
+        assert len(seen) == 3                                                # all three slots took their turn
+        h, rows, lens = e.batch_acquire(10, gen.row_dwords)
+        e.batch_release(h)
+        h, rows, lens = e.batch_acquire(10, gen.row_dwords)
+        lens[:] = 150
+        lens[3] = 161                                                        # does not fit a 10-word row
+        with pytest.raises(ValueError, match="exceeds row"):
+            e.batch_submit(h, 10)
+        h, rows, lens = e.batch_acquire(10, gen.row_dwords)
+        with pytest.raises(ValueError, match="more reads"):
+            e.batch_submit(h, 11)
+        assert e.finish_dict() == oracle.count((data, offs), ads, n_threads=8)
+        assert e.stats()["reads"] == n

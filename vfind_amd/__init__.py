@@ -102,6 +102,21 @@ class Engine:
         lens = np.ascontiguousarray(lens, dtype=np.uint16)
         check(self._L.vf_submit_packed(self._ctx, rows.ctypes.data, rows.shape[1], lens.ctypes.data, rows.shape[0]))
 
+    def batch_acquire(self, n_reads: int, row_dwords: int):
+        """page-locked staging of a free batch slot: (handle, rows uint32 [n, W], lens uint16 [n]) as numpy views of the
+        library's memory; fill them, then batch_submit(handle, n) -- the views are invalid afterwards"""
+        h, rows, lens = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(self._L.vf_batch_acquire(self._ctx, n_reads, row_dwords, C.byref(h), C.byref(rows), C.byref(lens)))
+        r = np.ctypeslib.as_array(C.cast(rows, C.POINTER(C.c_uint32)), (n_reads, row_dwords))
+        l = np.ctypeslib.as_array(C.cast(lens, C.POINTER(C.c_uint16)), (n_reads,))
+        return h, r, l
+
+    def batch_submit(self, handle, n_reads: int):
+        check(self._L.vf_batch_submit(self._ctx, handle, n_reads))
+
+    def batch_release(self, handle):
+        check(self._L.vf_batch_release(self._ctx, handle))
+
     def process_device(self, rows_ptr: int, row_dwords: int, lens_ptr: int, n_reads: int, spans_ptr: int = 0):
         """packed batch resident in HBM (raw device addresses, e.g. tensor.data_ptr())"""
         check(self._L.vf_process_device_packed(self._ctx, rows_ptr, row_dwords, lens_ptr, n_reads, spans_ptr or None))

@@ -48,6 +48,9 @@ SYMBOLS = [
     ("vf_run_fastq", C.c_int, [_P, C.c_char_p]),
     ("vf_submit_ascii", C.c_int, [_P, _P, _P, C.c_uint64]),
     ("vf_submit_packed", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint64]),
+    ("vf_batch_acquire", C.c_int, [_P, C.c_uint64, C.c_uint32, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    ("vf_batch_submit", C.c_int, [_P, _P, C.c_uint64]),
+    ("vf_batch_release", C.c_int, [_P, _P]),
     ("vf_process_device_packed", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint64, _P]),
     ("vf_spans_ascii", C.c_int, [_P, _P, _P, C.c_uint64, _P, _P]),
     ("vf_sync", C.c_int, [_P]),

@@ -145,6 +145,9 @@ struct Slot {
     DevBuf<uint32_t> d_tile_cnt, d_tile_off, d_line_end, d_info, d_gen_start, d_gen_len;
     PinBuf<uint32_t> h_info;
     bool text_pending = false;   // h_info of the latest text batch has not been looked at yet
+    uint64_t last_use = 0;       // ticket of the latest acquire (acquire_slot takes the free slot with the oldest one)
+    uint64_t batch_cap = 0;      // reads the staging was acquired for (vf_batch_acquire), 0 = not handed out
+    uint32_t batch_W = 0;
 };
 
 }  // namespace
@@ -174,6 +177,7 @@ struct vf_ctx {
     std::vector<std::unique_ptr<Slot>> slots;
     std::mutex mu;
     std::condition_variable cv;
+    uint64_t slot_ticket = 0;
     hipStream_t main_stream = nullptr;
     hipEvent_t clear_event = nullptr;   // recorded on main_stream after each table clear
     static constexpr int kMaxResLanes = 4;
@@ -661,14 +665,18 @@ static int run_generic(vf_ctx *c, Slot &s, uint64_t ng, uint64_t nbytes, uint32_
 // ------------------------------------------------------------------------------------------------
 // slots
 // ------------------------------------------------------------------------------------------------
+// The free slot that was handed out longest ago: a single submitting thread then walks round the slots, so the copy of
+// batch k + 1 really overlaps the kernels of batch k (taking the FIRST free slot gave that thread slot 0 every time and it
+// waited for its own previous batch: no overlap at all unless several threads submitted at once).
 static Slot *acquire_slot(vf_ctx *c) {
     std::unique_lock<std::mutex> lk(c->mu);
     Slot *s = nullptr;
     c->cv.wait(lk, [&] {
-        for (auto &x : c->slots) if (!x->busy) { s = x.get(); return true; }
-        return false;
+        for (auto &x : c->slots) if (!x->busy && (!s || x->last_use < s->last_use)) s = x.get();
+        return s != nullptr;
     });
     s->busy = true;
+    s->last_use = ++c->slot_ticket;
     return s;
 }
 static void release_slot(vf_ctx *c, Slot *s) {
@@ -885,6 +893,60 @@ extern "C" int vf_submit_packed(vf_ctx *c, const uint32_t *rows, uint32_t W, con
         s->in_flight = true;
         c->n_reads += m;
     }
+    return VF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pinned batches: the caller decodes straight into a slot's page-locked staging (north_star: "decoded on the host into
+// pinned packed-base buffers and streamed to HBM via hipMemcpyAsync overlapped with the previous batch").
+// vf_submit_packed takes ordinary host memory and has to copy it into that staging first: 22 GB/s instead of the link's rate.
+// ------------------------------------------------------------------------------------------------
+extern "C" int vf_batch_acquire(vf_ctx *c, uint64_t n_reads, uint32_t W, vf_batch **out, uint32_t **rows, uint16_t **lens) {
+    if (!c || !out || !rows || !lens) return fail(VF_EINVAL, "null argument");
+    *out = nullptr;
+    if (!c->fast_ok) return fail(VF_EINVAL, "these adapters/scores need the byte-wise path: use vf_submit_ascii");
+    if (W != 10 && W != 20 && W != 40) return fail(VF_EINVAL, "row_dwords must be 10, 20 or 40");
+    if (n_reads == 0 || n_reads > 0xFFFFFFF0ull) return fail(VF_EINVAL, "n_reads out of range");
+    HIP_TRY(hipSetDevice(c->dev));
+    Slot *s = acquire_slot(c);                                  // owned by the caller until vf_batch_submit / _release
+    int rc;
+    if ((rc = wait_slot(c, s)) || (rc = s->h_rows.ensure((size_t)n_reads * W)) || (rc = s->h_lens.ensure(n_reads))) { release_slot(c, s); return rc; }
+    s->batch_cap = n_reads; s->batch_W = W;
+    *rows = s->h_rows.p; *lens = s->h_lens.p;
+    *out = reinterpret_cast<vf_batch *>(s);
+    return VF_OK;
+}
+extern "C" int vf_batch_release(vf_ctx *c, vf_batch *b) {
+    if (!c || !b) return fail(VF_EINVAL, "null argument");
+    Slot *s = reinterpret_cast<Slot *>(b);
+    s->batch_cap = 0;
+    release_slot(c, s);
+    return VF_OK;
+}
+extern "C" int vf_batch_submit(vf_ctx *c, vf_batch *b, uint64_t n) {
+    if (!c || !b) return fail(VF_EINVAL, "null argument");
+    Slot *s = reinterpret_cast<Slot *>(b);
+    struct Rel { vf_ctx *c; Slot *s; ~Rel() { s->batch_cap = 0; release_slot(c, s); } } rel{c, s};
+    if (n > s->batch_cap) return fail(VF_EINVAL, "more reads than the batch was acquired for");
+    if (n == 0) return VF_OK;
+    const uint32_t W = s->batch_W;
+    HIP_TRY(hipSetDevice(c->dev));
+    uint64_t need = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (s->h_lens.p[i] > W * 16u) return fail(VF_EINVAL, "read length exceeds row");
+        need += arena_need(c, s->h_lens.p[i]);
+    }
+    int rc;
+    CapacityTicket ticket{c};
+    if ((rc = reserve_capacity(c, ticket, n, need))) return rc;
+    std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
+    if ((rc = s->d_rows.ensure((size_t)n * W)) || (rc = s->d_lens.ensure(n)) || (rc = s->ws.ensure(n))) return rc;
+    HIP_TRY(hipMemcpyAsync(s->d_rows.p, s->h_rows.p, (size_t)n * W * 4, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->d_lens.p, s->h_lens.p, n * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
+    if ((rc = run_packed(c, s->stream, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, n, s->ws.spans.p, true, s->h_entries.p))) return rc;
+    HIP_TRY(hipEventRecord(s->done, s->stream));
+    s->in_flight = true;
+    c->n_reads += n;
     return VF_OK;
 }
 
