@@ -52,7 +52,7 @@ def tie_sensitive_fraction(data, offs, ads, oracle, budget_s=8.0, max_reads=400)
                     "kernel == oracle there under tie policy P, oracle == parasail is unpinned"}
 
 
-def pcie_inclusive_leg(vfind_amd, gen, ads, n, L, device, slots, host_threads, rounds=3, queue_len=4):
+def pcie_inclusive_leg(vfind_amd, gen, ads, n, L, device, slots, host_threads, rounds=3, queue_len=8):
     """reads/s with the batches in page-locked HOST memory when the clock starts: vf_batch_acquire / vf_batch_submit, queue_len
     slots, hipMemcpyAsync of batch k + 1 overlapped with the kernels of batch k.  The staging is filled once (the host decoder's
     own speed is not part of this leg) and re-submitted `rounds` times."""

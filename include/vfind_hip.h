@@ -83,6 +83,7 @@ typedef struct vf_stats {
     uint64_t arena_top;        /* dwords of the long-key arena handed out so far (keys longer than 56 bytes live there) */
     double ms_result_build;    /* wall time of the latest vf_finish: table export, device dedupe + sort, copy of the frame */
     uint64_t result_rows;      /* rows of that frame */
+    uint64_t dbg[4];           /* diagnosis build only (insert-path batches, loop trips, CAS issued, CAS won); 0 in the product */
 } vf_stats;
 
 const char *vf_last_error(void);

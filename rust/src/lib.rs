@@ -6,44 +6,11 @@ use polars_arrow::ffi;
 use pyo3::exceptions::{PyOSError, PyRuntimeError, PyValueError};
 use pyo3::prelude::*;
 use pyo3_polars::PyDataFrame;
-use std::ffi::{c_char, c_int, CStr, CString};
+use std::ffi::{c_int, CStr, CString};
 use std::fs::File;
 
-#[repr(C)]
-struct VfParams {
-    prefix: *const u8,
-    prefix_len: u32,
-    suffix: *const u8,
-    suffix_len: u32,
-    match_score: i32,
-    mismatch_score: i32,
-    gap_open_penalty: i32,
-    gap_extend_penalty: i32,
-    accept_prefix_alignment: f64,
-    accept_suffix_alignment: f64,
-    n_threads: u32,
-    queue_len: u32,
-    skip_translation: i32,
-    device: i32,
-    table_slots: u64,
-    arena_bytes: u64,
-    batch_reads: u32,
-    reserved: u32,
-}
-#[repr(C)]
-struct VfCtx { _p: [u8; 0] }
-#[repr(C)]
-struct VfResult { _p: [u8; 0] }
-
-extern "C" {
-    fn vf_last_error() -> *const c_char;
-    fn vf_ctx_create(p: *const VfParams, out: *mut *mut VfCtx) -> c_int;
-    fn vf_ctx_destroy(ctx: *mut VfCtx);
-    fn vf_run_fastq(ctx: *mut VfCtx, path: *const c_char) -> c_int;
-    fn vf_finish(ctx: *mut VfCtx, out: *mut *mut VfResult) -> c_int;
-    fn vf_result_export_arrow(r: *mut VfResult, array: *mut ffi::ArrowArray, schema: *mut ffi::ArrowSchema) -> c_int;
-    fn vf_result_free(r: *mut VfResult);
-}
+mod vf_abi;
+use vf_abi::*;
 
 /// VF_EINVAL -> ValueError (same text as the reference's preflight), VF_EIO -> OSError, else RuntimeError
 fn check(rc: c_int) -> PyResult<()> {

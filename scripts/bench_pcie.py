@@ -1,20 +1,28 @@
-"""PCIe-inclusive rate: packed reads in ordinary host memory -> vf_submit_packed (copy into pinned staging,
-hipMemcpyAsync, kernels overlapped over queue_len slots) -> table.  Never the headline `value`."""
-import sys, os, time
+"""PCIe-inclusive rate through the pinned batch API (vf_batch_acquire / vf_batch_submit): the staging of every slot is
+filled once (the generator is far slower than the link) and re-submitted; variants of queue_len and batch size.
+Never the headline `value`."""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import vfind_amd
 from benchlib import synth
 n = 10_000_000
 ads = synth.adapters(0x5EED0002, 20)
 gen = synth.Generator(0x5EED0002, ads)
-rows, lens = gen.packed(0, n, 16)
-for ql, br, nt in ((2, 1 << 18, 3), (4, 1 << 20, 3), (4, 1 << 20, 8), (4, 1 << 20, 16)):
-    eng = vfind_amd.Engine(ads, queue_len=ql, batch_reads=br, n_threads=nt, table_slots=1 << 22)
-    eng.submit_packed(rows[:1 << 20], lens[:1 << 20]); eng.sync(); eng.clear()
+for ql, nb in ((2, 5_000_000), (4, 2_500_000), (4, 1_000_000), (8, 1_250_000), (8, 500_000), (3, 3_000_000)):
+    eng = vfind_amd.Engine(ads, queue_len=ql, table_slots=1 << 21)
+    W = gen.row_dwords
+    for k in range(ql):
+        h, r, l = eng.batch_acquire(nb, W)
+        gen.packed_into(k * nb, nb, r.ctypes.data, l.ctypes.data, 16)
+        eng.batch_submit(h, nb)
+    eng.sync(); eng.clear()
+    rounds = max(3, 40_000_000 // (ql * nb))
     t0 = time.perf_counter()
-    eng.submit_packed(rows, lens)
+    for _ in range(rounds * ql):
+        h, r, l = eng.batch_acquire(nb, W)
+        eng.batch_submit(h, nb)
     eng.sync()
     dt = time.perf_counter() - t0
-    print(f"queue_len={ql} batch_reads={br} n_threads={nt}: {n/dt/1e6:.1f} M reads/s ({n*42/dt/1e9:.2f} GB/s algorithmic, {n*40/dt/1e9:.1f} GB/s over PCIe)", flush=True)
+    reads = rounds * ql * nb
+    print(f"queue_len={ql} batch={nb}: {reads/dt/1e6:.1f} M reads/s, {reads*(W*4+2)/dt/1e9:.2f} GB/s over the link", flush=True)
     eng.close()

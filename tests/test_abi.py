@@ -109,3 +109,17 @@ def test_pack_read_matches_a_plain_packer():
             want[i // 16] |= np.uint32(code[int(c)] << (2 * (i % 16)))
         assert rc == 0 and (row == want).all(), (t, n)
     assert L.vf_pack_read(np.frombuffer(b"A" * 161, np.uint8).ctypes.data, 161, np.zeros(10, np.uint32).ctypes.data, 10) == 1
+
+
+def test_rust_shim_declares_the_same_entry_points():
+    """rust/ is source only here (no rustc): its extern "C" block must at least name exactly the functions the header declares,
+    and its vf_stats mirror must have as many 8-byte fields as the C struct"""
+    hdr = open(os.path.join(ROOT, "include", "vfind_hip.h")).read()
+    declared = set(re.findall(r"\b(vf_[a-z0-9_]+)\s*\(", hdr)) - {"vf_params", "vf_ctx", "vf_result", "vf_stats", "vf_batch"}
+    rs = open(os.path.join(ROOT, "rust", "src", "vf_abi.rs")).read()
+    assert set(re.findall(r"pub fn (vf_[a-z0-9_]+)\(", rs)) == declared
+    from vfind_amd import _lib
+    import ctypes as C
+    body = rs[rs.index("pub struct VfStats"):rs.index('extern "C" {')]
+    n_fields = len(re.findall(r"pub [a-z0-9_]+: (?:u64|f64)", body)) + 4 * len(re.findall(r"\[u64; 4\]", body))
+    assert n_fields * 8 == C.sizeof(_lib.VfStats)

@@ -31,6 +31,8 @@ struct DpParams {
     uint32_t eq[4];      // eq[c] bit i set <=> adapter base i == c
     int32_t T;           // accept iff score >= T
     int32_t mismatch;    // for un-biasing
+    int32_t match, gopen, gext;   // plain scoring values (dp_coop)
+    uint32_t coop_max;            // classes 3 / 4 of at most this many tasks run one task per wave (dp_coop); 0 = never
     int32_t e_open_k, e_ext_k, f_open_k, f_ext_k;  // packed additive constants
     uint32_t delta;      // (match - mismatch) << kScoreShift
     uint32_t is_prefix;
@@ -82,7 +84,11 @@ enum Counter : int {        // uint64 counters[] in device memory
     C_EXPORT_N = 8,
     C_EXPORT_KEYS = 9,
     C_SLOW = 10,            // reads k_finish sent through the insert path (one-shot lookup missed)
-    C_NUM = 11
+    C_DBG0 = 11,            // diagnosis build only (make ablation): insert-path batches of a wave,
+    C_DBG1 = 12,            //   trips of their claim/publish loop,
+    C_DBG2 = 13,            //   claiming CAS issued,
+    C_DBG3 = 14,            //   claiming CAS won
+    C_NUM = 15
 };
 constexpr int kTableCounters = 4;       // C_ARENA_TOP..C_KEY_DWORDS are reset with the table
 

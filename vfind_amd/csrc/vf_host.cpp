@@ -263,6 +263,9 @@ static void fill_dp(DpParams &d, const std::string &ad, int64_t T, const vf_ctx 
     for (size_t i = 0; i < ad.size(); ++i) d.eq[base_code((unsigned char)ad[i]) & 3u] |= 1u << i;
     d.T = (int32_t)std::max<int64_t>(std::min<int64_t>(T, INT32_MAX), INT32_MIN + 1);
     d.mismatch = c.mismatch;
+    d.match = c.match; d.gopen = c.gopen; d.gext = c.gext;
+    static const uint32_t coop_max = [] { const char *e = getenv("VFIND_DP_COOP_MAX"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 4096u; }();
+    d.coop_max = coop_max;
     const int32_t S = 1 << kScoreShift, P = 1 << kPrefShift;
     d.e_open_k = -c.gopen * S + 1;                             // H(pref 0) -> pref 0, len+1
     d.e_ext_k = -c.gext * S + 1 * P + 1;                      // E(pref 0) -> pref 1, len+1
@@ -1390,6 +1393,7 @@ extern "C" int vf_stats_get(vf_ctx *c, vf_stats *o) {
     o->ms_scan = c->ms[K_SCAN]; o->ms_filter = c->ms[K_FILTER]; o->ms_dp_window = c->ms[K_DPW]; o->ms_dp_rest = c->ms[K_DPREST];
     o->ms_finish = c->ms[K_FIN]; o->ms_generic = c->ms[K_GEN];
     o->ms_result_build = c->ms_result; o->result_rows = c->result_rows;
+    for (int k = 0; k < 4; ++k) o->dbg[k] = h[C_DBG0 + k];
     o->launches_scan = c->launches[K_SCAN]; o->launches_filter = c->launches[K_FILTER];
     o->launches_dp_window = c->launches[K_DPW]; o->launches_dp_rest = c->launches[K_DPREST];
     o->launches_finish = c->launches[K_FIN]; o->launches_generic = c->launches[K_GEN];
@@ -1404,6 +1408,7 @@ extern "C" int vf_stats_reset(vf_ctx *c) {
     const uint64_t z[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(c->t_counters.p + C_ACCEPTED, z, 4 * sizeof(uint64_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->t_counters.p + C_SLOW, z, sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->t_counters.p + C_DBG0, z, 4 * sizeof(uint64_t), hipMemcpyHostToDevice));
     return VF_OK;
 }
 extern "C" int vf_set_profiling(vf_ctx *c, int on) {

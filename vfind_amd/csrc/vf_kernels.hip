@@ -836,11 +836,13 @@ __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ 
 // Stages of k_bmfilter (block filter, then Myers pass over what it left), written as per-workgroup loops over a task
 // segment that fetch the task of the next trip while they work on the current one (task index two trips ahead, row one
 // trip ahead).
-// (Round 2 also built k_front: exact scan, both block filters and the prefix Myers pass as ONE persistent kernel, every
-// list workgroup-local.  It gave bit-identical results and took exactly as long as its parts -- 448 us against 439 us for
-// scan + 2 block filters + Myers pass on one batch lane -- because all workgroups walk through the stages in step, so
-// nothing overlaps; next to the other lane's k_finish it was slower, 1.04-1.15 against 0.93 ms per step, its 94 registers
-// leaving the scan stage fewer waves than k_scan's 72.  Removed again)
+// Round 2 tried three other shapes of this stage, all bit-identical in their results, none faster where it counts (cfg 2, two
+// batch lanes; DESIGN.md section 8 has the numbers): two per-segment launches (block filter 51 us + Myers pass of the rest
+// 52 us on one lane, against 115 us for this kernel, but 0.98 against 0.91 ms per step next to the other lane's k_finish);
+// k_front, a persistent kernel with scan, both block filters and the prefix Myers pass, every list workgroup-local (448 us
+// against 439 us for its parts: all workgroups walk through the stages in step, nothing overlaps; 1.04-1.15 ms per step);
+// and two FLAT launches (every workgroup an equal share of all tasks through a prefix sum over the segments: 50 + 69 us on
+// one lane, 1.02-1.06 ms per step).
 // ------------------------------------------------------------------------------------------------
 // trips of one wave over a task list of the workgroup: lane l of wave w takes tasks w*64 + l + 256 i
 struct TripIter {
@@ -1179,6 +1181,96 @@ __device__ __forceinline__ void dpb_body(FlatList &fl, DpLds &L, const uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------
+// dp_coop: the DP of ONE task by one whole wave -- an adapter row per lane, anti-diagonal by anti-diagonal -- for the rare
+// classes whose single-lane DP is the launch's tail: a whole read (class 4) costs one lane 150 x 20 cells = 33 000
+// instructions, 70 us with the wave alone on its SIMD, and k_dpall could not end before it; two windows (class 3) 30-40 us.
+// Here lane i holds row i + 1; at step t it computes the cell of column j = t - i from its own previous cell (west), the
+// cell lane i - 1 computed a step ago (north: one cross-lane move) and the one it computed two steps ago (north-west,
+// kept from the previous step): n + M - 1 steps of about 35 instructions.  Plain int32 score / length pairs and the tie
+// rules written out as in k_generic's g_sg (open only if strictly greater; diagonal, then north, then west; last row
+// strictly greater from the left, last-column rows strictly greater from the top) -- policy P, no packed cell.
+// Columns (a, b] of the read: a == 0 is the true first column, otherwise everything left of a is off all accepting paths
+// (-inf); for two windows the hull (a1, b2] is computed -- cells between the windows that the windowed DP lowers to -inf
+// get some value not above their true one here, which changes no cell on an accepting path.
+// ------------------------------------------------------------------------------------------------
+template <int M>
+__device__ __forceinline__ void dp_coop(const uint32_t *__restrict__ row, int W, int n, int a, int b, const DpParams &dp, uint32_t *s_row,
+                                        int &score, int &len) {
+    const int lane = (int)lane_id();
+    constexpr int NEG = INT32_MIN / 4;
+    if (lane < W) s_row[lane] = row[lane];                   // W <= 40: the task's row, wave-private LDS
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool rowlane = lane < M;
+    const uint32_t qc = rowlane ? (uint32_t)(dp.pat >> (2 * lane)) & 3u : 0u;
+    const int match = dp.match, mismatch = dp.mismatch, gopen = dp.gopen, gext = dp.gext;
+    int h = a == 0 ? 0 : NEG, hl = 0, e = NEG, el = 0, f = NEG, fl = 0;      // this row's cell at column a
+    int dg_h = 0, dg_hl = 0;                                  // H[i-1][j-1]: row 0 for lane 0, column a for the others at their first step
+    if (lane > 0) dg_h = a == 0 ? 0 : NEG;
+    int best = NEG, bestl = 0, colh = NEG, colhl = 0;
+    const int cols = b - a;
+    for (int t = 1; t <= cols + M - 1; ++t) {
+        int uh = __shfl_up(h, 1), uhl = __shfl_up(hl, 1), uf = __shfl_up(f, 1), ufl = __shfl_up(fl, 1);
+        if (lane == 0) { uh = 0; uhl = 0; uf = NEG; ufl = 0; }       // row 0: free start anywhere in the read
+        const int jr = t - lane;                                  // column relative to a, 1-based
+        if (rowlane && jr >= 1 && jr <= cols) {
+            const int j = a + jr;
+            const uint32_t wd = s_row[(j - 1) >> 4];
+            const uint32_t rc = (wd >> (2 * ((j - 1) & 15))) & 3u;
+            const int eo = h - gopen, ee = e - gext;
+            int ne, nel;
+            if (eo > ee) { ne = eo; nel = hl + 1; } else { ne = ee; nel = el + 1; }
+            const int fo = uh - gopen, fe = uf - gext;
+            int nf, nfl;
+            if (fo > fe) { nf = fo; nfl = uhl + 1; } else { nf = fe; nfl = ufl + 1; }
+            const int d = dg_h + (qc == rc ? match : mismatch), dl = dg_hl + 1;
+            const int nh = max(d, max(ne, nf));
+            const int nhl = nh == d ? dl : (nh == nf ? nfl : nel);
+            h = nh; hl = nhl; e = ne; el = nel; f = nf; fl = nfl;
+            if (lane == M - 1 && nh > best) { best = nh; bestl = nhl; }
+            if (j == n) { colh = nh; colhl = nhl; }
+        }
+        dg_h = uh; dg_hl = uhl;
+    }
+    int bs = __shfl(best, M - 1), bl_ = __shfl(bestl, M - 1);
+    if (b == n) {
+#pragma unroll 1
+        for (int i = 0; i < M - 1; ++i) {
+            const int ci = __shfl(colh, i), cl = __shfl(colhl, i);
+            if (ci > bs) { bs = ci; bl_ = cl; }
+        }
+    }
+    score = bs; len = bl_;
+}
+
+// classes 3 (two windows: their hull) and 4 (whole read), one task per wave
+template <int M>
+__device__ __forceinline__ void dpc_body(FlatList &fl, const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
+                                         const DpParams &dp, short2 *__restrict__ spans, const BatchLists &bl, bool two_windows,
+                                         uint32_t *s_rows, uint32_t bid, uint32_t nb) {
+    const uint32_t *list = two_windows ? bl.listW[3] : bl.listF;
+    flat_build(fl, two_windows ? bl.cntW[3] : bl.cntF, bl.grid);
+    const uint32_t total = fl.pre[kMaxGrid];
+    const uint32_t wave = threadIdx.x / WAVE, nwaves = kBlock / WAVE;
+    uint32_t *s_row = s_rows + wave * 40;
+    for (uint32_t t = bid * nwaves + wave; t < total; t += nb * nwaves) {          // wave-uniform
+        const uint32_t seg = flat_segment(fl, t);
+        const uint64_t at = (uint64_t)seg * bl.seg + (t - fl.pre[seg]);
+        const uint32_t r = list[at];
+        const int n = lens[r];
+        int a = 0, b = n;
+        if (two_windows) { a = (int)(bl.winW[3][at] & 0xFFFFu); b = (int)(bl.winW2[at] >> 16); }
+        int score = INT32_MIN / 2, len = 0;
+        if (b - a > 0) dp_coop<M>(rows + (uint64_t)r * W, W, n, a, b, dp, s_row, score, len);
+        const bool lead = lane_id() == 0;
+        const bool pushS = dp_commit(lead, r, n, score >= dp.T, len, dp, spans);
+        if (dp.is_prefix) push_suffix(bl, seg, r, pushS);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_dpall: every task class of one filter pass in ONE launch.  The filter leaves the number of tasks per class
 // in bl.tot; every workgroup derives the same split of the grid from them -- blocks in proportion to tasks x
 // cells per task, at least one block for a class that has tasks, no more blocks than the class has waves --
@@ -1192,22 +1284,33 @@ __global__ __launch_bounds__(kBlock) void k_dpall(const uint32_t *__restrict__ r
                                                   DpParams dp, short2 *__restrict__ spans, BatchLists bl, uint64_t *__restrict__ counters) {
     __shared__ FlatList fl;
     __shared__ DpLds L;
+    __shared__ uint32_t s_rows[(kBlock / WAVE) * 40];
     const uint32_t *tot = bl.tot + (dp.is_prefix ? 0u : 8u);
     // relative cost of a task: banded M x kBand cells; one window ~ M x (m + kerr + 8); long / two windows ~ M x 64 x 1..2;
     // full width M x read length
-    // index 5 = the narrow band of the block filter (M x kBandN cells)
-    const uint32_t cost[6] = {4u, 16u, 32u, 48u, 128u, 2u};
+    // index 5 = the narrow band of the block filter (M x kBandN cells).  Classes 3 and 4 (two windows, whole read) are a
+    // handful of tasks in a low-error library: then they run one task per WAVE (dp_coop, ~12 us a task instead of 30-70 us for
+    // one lane), and a task costs a wave what 64 lanes of the other classes cost it together; as big classes (15 % adapter
+    // errors: 75 000 two-window tasks) they stay one task per lane.
+    uint32_t cost[6] = {4u, 16u, 32u, 48u, 128u, 2u};
     uint32_t nbk[6], t5[6];
     uint64_t wsum = 0;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) { t5[q] = __builtin_amdgcn_readfirstlane(tot[q]); wsum += (uint64_t)t5[q] * cost[q]; }
+    for (int q = 0; q < 6; ++q) t5[q] = __builtin_amdgcn_readfirstlane(tot[q]);
+    const bool coop3 = t5[3] <= dp.coop_max, coop4 = t5[4] <= dp.coop_max;
+    if (coop3) cost[3] = 600u;
+    if (coop4) cost[4] = 600u;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) wsum += (uint64_t)t5[q] * cost[q];
     if (wsum == 0) return;
     const uint32_t G = gridDim.x;
     uint32_t used = 0;
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
         uint32_t b = t5[q] ? (uint32_t)((uint64_t)G * t5[q] * cost[q] / wsum) : 0u;
-        const uint32_t cap = (t5[q] + kBlock - 1) / kBlock;              // one workgroup per 256 tasks at most
+        // one workgroup per 256 tasks at most; classes 3 and 4 run one task per WAVE (dp_coop): one workgroup per 4 tasks
+        const uint32_t per_wg = ((q == 3 && coop3) || (q == 4 && coop4)) ? (uint32_t)(kBlock / WAVE) : (uint32_t)kBlock;
+        const uint32_t cap = (t5[q] + per_wg - 1) / per_wg;
         if (t5[q] && b < 1) b = 1;
         if (q > 0 && q < 5 && cap <= 2 * b + 8) b = cap;                   // a small class runs as one trip: its latency is the launch's tail
         if (b > cap) b = cap;
@@ -1236,9 +1339,16 @@ __global__ __launch_bounds__(kBlock) void k_dpall(const uint32_t *__restrict__ r
     b0 += nbk[1];
     if (b < b0 + nbk[2]) { dpw_body<M, false>(fl, L, rows, lens, W, dp, spans, bl, 2, b - b0, nbk[2]); return; }
     b0 += nbk[2];
-    if (b < b0 + nbk[3]) { dpw_body<M, true>(fl, L, rows, lens, W, dp, spans, bl, 3, b - b0, nbk[3]); return; }
+    if (b < b0 + nbk[3]) {
+        if (coop3) dpc_body<M>(fl, rows, lens, W, dp, spans, bl, true, s_rows, b - b0, nbk[3]);
+        else dpw_body<M, true>(fl, L, rows, lens, W, dp, spans, bl, 3, b - b0, nbk[3]);
+        return;
+    }
     b0 += nbk[3];
-    if (b < b0 + nbk[4]) dp_full_body<M>(fl, L, rows, lens, W, dp, spans, bl, bl.listF, bl.cntF, 0u, counters, b - b0, nbk[4]);
+    if (b < b0 + nbk[4]) {
+        if (coop4) dpc_body<M>(fl, rows, lens, W, dp, spans, bl, false, s_rows, b - b0, nbk[4]);
+        else dp_full_body<M>(fl, L, rows, lens, W, dp, spans, bl, bl.listF, bl.cntF, 0u, counters, b - b0, nbk[4]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1434,7 +1544,13 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
     // finds a slot claimed but not yet published simply looks again on the next trip; because the
     // claiming lane (possibly in this very wave) publishes inside the loop body, before the vote,
     // the wait cannot deadlock and the compiler cannot sink the publish past the loop exit.
+#ifdef VF_FINISH_ABLATION
+    if (lane_id() == 0) atomicAdd((unsigned long long *)&t.counters[C_DBG0], 1ull);
+#endif
     while (__any(!done)) {
+#ifdef VF_FINISH_ABLATION
+        if (lane_id() == 0) atomicAdd((unsigned long long *)&t.counters[C_DBG1], 1ull);
+#endif
         if (!done) {
             uint4 *sp = t.slots + (uint64_t)slot * 4;
             bool advance = false;
@@ -1446,6 +1562,10 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
                 if (w0 == 0ull) {
                     w0 = atomicCAS(reinterpret_cast<unsigned long long *>(sp), 0ull, (unsigned long long)w0claim);
                     claimed = w0 == 0ull;
+#ifdef VF_FINISH_ABLATION
+                    atomicAdd((unsigned long long *)&t.counters[C_DBG2], 1ull);
+                    if (claimed) atomicAdd((unsigned long long *)&t.counters[C_DBG3], 1ull);
+#endif
                 }
             }
             if (claimed) {
