@@ -407,7 +407,7 @@ def main():
         # rocprofv3 --pmc runs of this same workload, gfx950 FETCH_SIZE correction applied there)
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")))["kernels"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")))["kernels"]
             prefix = {"scan": "vf::k_scan<10", "finish": "vf::k_finish<10"}.get(dom)
             if prefix and L == 150 and n == 10_000_000:
                 traffic = next((v.get("traffic") for k, v in pmc.items() if k.startswith(prefix)), None)

@@ -1,4 +1,4 @@
-"""profiles/r01_pmc_hbm.json from two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE) of
+"""profiles/r02_pmc_hbm.json from two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE) of
 `VFIND_RES_LANES=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity`.
 usage: pmc_hbm.py fetch_counter_collection.csv write_counter_collection.csv out.json [n_reads row_bytes]"""
 import csv, json, re, sys, collections
@@ -16,7 +16,7 @@ n = int(sys.argv[4]) if len(sys.argv) > 4 else 10_000_000
 row_b = int(sys.argv[5]) if len(sys.argv) > 5 else 40
 out = {
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (each with --kernel-trace only) of "
-              "`VFIND_RES_LANES=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity` (one batch lane, so no two "
+              "`VFIND_RES_LANES=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-extras` (one batch lane, so no two "
               "batches' kernels overlap in the counters); per-launch averages over the full-size launches, KB as reported x 1024.",
     "gfx950_correction": "FETCH_SIZE tallies 128-B streaming requests as 64 B (MI355X_MICROARCH.md, HBM). Calibrated on k_scan, whose "
                          "only fetches are the packed rows + lengths: it reports about half the known bytes, so the streaming part of "

@@ -264,7 +264,7 @@ static void fill_dp(DpParams &d, const std::string &ad, int64_t T, const vf_ctx 
     d.T = (int32_t)std::max<int64_t>(std::min<int64_t>(T, INT32_MAX), INT32_MIN + 1);
     d.mismatch = c.mismatch;
     d.match = c.match; d.gopen = c.gopen; d.gext = c.gext;
-    static const uint32_t coop_max = [] { const char *e = getenv("VFIND_DP_COOP_MAX"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 4096u; }();
+    static const uint32_t coop_max = [] { const char *e = getenv("VFIND_DP_COOP_MAX"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 256u; }();
     d.coop_max = coop_max;
     const int32_t S = 1 << kScoreShift, P = 1 << kPrefShift;
     d.e_open_k = -c.gopen * S + 1;                             // H(pref 0) -> pref 0, len+1

@@ -2,7 +2,9 @@
 #pragma once
 #include <stdint.h>
 
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 struct vf_ctx;
@@ -23,9 +25,19 @@ int vf_internal_fail(int code, const std::string &msg);      // sets the calling
 std::string vf_internal_last_error();
 
 // the (sequence, count) frame handed over the ABI (lib.rs:312-319): rows sorted count desc, sequence asc
+// (vector storage that resize() leaves uninitialised: the buffers are filled by a device-to-host copy, and zeroing 600 MB
+// first cost more than the copy)
+template <class T> struct VfNoInit : std::allocator<T> {
+    template <class U> struct rebind { using other = VfNoInit<U>; };
+    VfNoInit() = default;
+    template <class U> VfNoInit(const VfNoInit<U> &) {}
+    template <class U, class... A> void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
 struct vf_result {
-    std::vector<uint8_t> keys;        // concatenated UTF-8 keys
-    std::vector<uint64_t> offsets;    // rows + 1
-    std::vector<uint64_t> counts;     // rows
+    std::vector<uint8_t, VfNoInit<uint8_t>> keys;        // concatenated UTF-8 keys
+    std::vector<uint64_t, VfNoInit<uint64_t>> offsets;   // rows + 1
+    std::vector<uint64_t, VfNoInit<uint64_t>> counts;    // rows
 };
 

@@ -14,8 +14,14 @@
 //   sort 2        groups by (count descending, string rank ascending): a total order, no reliance on stability
 //   k_rs_gather   offsets (scan of the lengths in final order), bytes and counts into the output buffers
 // The sorts are rocPRIM's device primitives; everything that touches keys is written here.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/vfind_hip.h"
@@ -220,6 +226,15 @@ int build_result_on_device(hipStream_t s, const uint64_t *d_refs, const uint64_t
                            bool check_utf8, vf_result &out, std::string &err) {
     out.keys.clear(); out.offsets.assign(1, 0); out.counts.clear();
     if (n == 0) return VF_OK;
+    static const bool timing = getenv("VFIND_RESULT_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[result] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     if (n >= 0xFFFFFFF0ull) { err = "table too large for the device result build"; return VF_ECAPACITY; }
     Dev blen, keep, boff, kpos, tmp;
     RS_TRY(blen.alloc(n * 8)); RS_TRY(keep.alloc(n * 4)); RS_TRY(boff.alloc((n + 1) * 8)); RS_TRY(kpos.alloc((n + 1) * 4));
@@ -240,6 +255,7 @@ int build_result_on_device(hipStream_t s, const uint64_t *d_refs, const uint64_t
     RS_TRY(hipMemcpyAsync(&last_keep, keep.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, s));
     RS_TRY(hipStreamSynchronize(s));
     const uint64_t total_bytes = last_off + last_len, m = (uint64_t)last_pos + last_keep;       // kept entries
+    lap("prep + scans");
     if (m == 0) return VF_OK;
 
     Dev bytes, ent, sk, sk2, head, gid;
@@ -247,12 +263,14 @@ int build_result_on_device(hipStream_t s, const uint64_t *d_refs, const uint64_t
     hipLaunchKernelGGL(k_rs_expand, dim3(blocks_for(n)), dim3(kRsBlock), 0, s, d_refs, d_counts, d_arena, n, boff.as<uint64_t>(), keep.as<uint32_t>(),
                        kpos.as<uint32_t>(), bytes.as<uint8_t>(), ent.as<Ent>(), sk.as<SortKey>());
     RS_TRY(hipGetLastError());
+    lap("expand");
     // sort 1: by string
     const StringLess less{bytes.as<uint8_t>(), ent.as<Ent>()};
     Dev t1;
     RS_TRY(rocprim::merge_sort(nullptr, tb3, sk.as<SortKey>(), sk2.as<SortKey>(), (size_t)m, less, s));
     RS_TRY(t1.alloc(tb3));
     RS_TRY(rocprim::merge_sort(t1.p, tb3, sk.as<SortKey>(), sk2.as<SortKey>(), (size_t)m, less, s));
+    lap("sort by string");
     // runs of equal strings -> groups
     RS_TRY(head.alloc(m * 4)); RS_TRY(gid.alloc(m * 4));
     hipLaunchKernelGGL(k_rs_heads, dim3(blocks_for(m)), dim3(kRsBlock), 0, s, sk2.as<SortKey>(), bytes.as<uint8_t>(), ent.as<Ent>(), m, head.as<uint32_t>());
@@ -272,6 +290,7 @@ int build_result_on_device(hipStream_t s, const uint64_t *d_refs, const uint64_t
     hipLaunchKernelGGL(k_rs_groups, dim3(blocks_for(m)), dim3(kRsBlock), 0, s, sk2.as<SortKey>(), ent.as<Ent>(), head.as<uint32_t>(), gid.as<uint32_t>(), m,
                        gcount.as<unsigned long long>(), grep.as<uint32_t>());
     RS_TRY(hipGetLastError());
+    lap("heads + groups");
     // sort 2: groups by (count descending, string ascending)
     hipLaunchKernelGGL(k_rs_iota, dim3(blocks_for(g)), dim3(kRsBlock), 0, s, order.as<uint32_t>(), g);
     RS_TRY(hipGetLastError());
@@ -281,6 +300,7 @@ int build_result_on_device(hipStream_t s, const uint64_t *d_refs, const uint64_t
     RS_TRY(rocprim::merge_sort(nullptr, tb5, order.as<uint32_t>(), order2.as<uint32_t>(), (size_t)g, gless, s));
     RS_TRY(t3.alloc(tb5));
     RS_TRY(rocprim::merge_sort(t3.p, tb5, order.as<uint32_t>(), order2.as<uint32_t>(), (size_t)g, gless, s));
+    lap("sort by count");
     // output buffers
     Dev olen, ooff, okeys, ooffs, ocnts, t4;
     RS_TRY(olen.alloc(g * 8)); RS_TRY(ooff.alloc(g * 8));
@@ -295,14 +315,42 @@ int build_result_on_device(hipStream_t s, const uint64_t *d_refs, const uint64_t
                        gcount.as<unsigned long long>(), ooff.as<uint64_t>(), bytes.as<uint8_t>(), g, okeys.as<uint8_t>(), ooffs.as<uint64_t>(),
                        ocnts.as<uint64_t>());
     RS_TRY(hipGetLastError());
+    lap("gather");
+    uint64_t out_bytes = 0;                                 // duplicates merged: at most total_bytes
+    RS_TRY(hipMemcpyAsync(&out_bytes, ooffs.as<uint64_t>() + g, 8, hipMemcpyDeviceToHost, s));
+    RS_TRY(hipStreamSynchronize(s));                        // s does not synchronise with the null stream the slice copies below use
+    if (out_bytes > total_bytes) { err = "result build: inconsistent key bytes"; return VF_EDEVICE; }
     out.offsets.resize(g + 1);
     out.counts.resize(g);
-    RS_TRY(hipMemcpyAsync(out.offsets.data(), ooffs.p, (g + 1) * 8, hipMemcpyDeviceToHost, s));
-    RS_TRY(hipMemcpyAsync(out.counts.data(), ocnts.p, g * 8, hipMemcpyDeviceToHost, s));
-    RS_TRY(hipStreamSynchronize(s));
-    const uint64_t out_bytes = out.offsets[g];              // duplicates merged: at most total_bytes
     out.keys.resize(out_bytes);
-    if (out_bytes) RS_TRY(hipMemcpy(out.keys.data(), okeys.p, out_bytes, hipMemcpyDeviceToHost));
+    // the three buffers come back in slices copied by several host threads at once: the destination is ordinary (pageable,
+    // freshly mapped) memory, so a copy is a DMA into the runtime's staging plus a CPU copy that also takes the page faults,
+    // and one thread doing all of it was 110 ms of a 140 ms vf_finish at 10^7 rows / 470 MB of strings
+    struct Piece { void *dst; const void *src; size_t n; };
+    std::vector<Piece> pieces;
+    auto add = [&](void *dst, const void *src, size_t nbytes) {
+        const size_t slice = 32u << 20;
+        for (size_t at = 0; at < nbytes; at += slice) pieces.push_back(Piece{(uint8_t *)dst + at, (const uint8_t *)src + at, std::min(slice, nbytes - at)});
+    };
+    add(out.offsets.data(), ooffs.p, (g + 1) * 8);
+    add(out.counts.data(), ocnts.p, g * 8);
+    add(out.keys.data(), okeys.p, out_bytes);
+    int dev = 0;
+    RS_TRY(hipGetDevice(&dev));
+    const unsigned nthreads = (unsigned)std::min<size_t>(8, pieces.size());
+    std::atomic<size_t> next{0};
+    std::atomic<int> bad{0};
+    auto work = [&] {
+        if (hipSetDevice(dev) != hipSuccess) { bad = 1; return; }
+        for (size_t i = next++; i < pieces.size(); i = next++)
+            if (hipMemcpy(pieces[i].dst, pieces[i].src, pieces[i].n, hipMemcpyDeviceToHost) != hipSuccess) bad = 1;
+    };
+    std::vector<std::thread> th;
+    for (unsigned k = 1; k < nthreads; ++k) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (bad) { err = "copy of the result frame failed"; return VF_EDEVICE; }
+    lap("copy back");
     return VF_OK;
 }
 
