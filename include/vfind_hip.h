@@ -172,7 +172,9 @@ int vf_table_clear(vf_ctx *ctx);
 /* Multi-GPU exchange of the (key,count) table (the reduce of lib.rs:292-306 across GPUs).
  * vf_table_export_size gives the byte size of this GPU's compacted table; vf_table_export
  * writes it to device memory the caller owns (e.g. an RCCL send buffer); vf_table_merge adds a
- * peer's exported table (device memory, e.g. an RCCL receive buffer) into this GPU's table. */
+ * peer's exported table (device memory, e.g. an RCCL receive buffer) into this GPU's table.
+ * Both calls return when the library's stream is done with the buffer; the library does not know the caller's streams:
+ * work the caller has queued on the buffer elsewhere (a fill, a copy, a collective) must have finished before the call. */
 int vf_table_export_size(vf_ctx *ctx, uint64_t *nbytes);
 int vf_table_export(vf_ctx *ctx, void *d_dst, uint64_t capacity, uint64_t *written);
 int vf_table_merge(vf_ctx *ctx, const void *d_blob, uint64_t nbytes);   /* makes room first (grows the table / key arena) */

@@ -741,7 +741,7 @@ def test_owner_partitioned_exchange_between_local_contexts():
         assert len(sizes) == 3 and all(s >= 16 for s in sizes)
         shares = []
         for o in range(3):
-            buf = torch.zeros(sizes[o] + 64, dtype=torch.uint8, device="cuda")
+            buf = torch.empty(sizes[o] + 64, dtype=torch.uint8, device="cuda")
             assert engines[1].partition_export(3, o, buf.data_ptr(), buf.numel()) == sizes[o]
             shares.append((buf, sizes[o]))
         own = engines[1].finish_dict()
@@ -779,7 +779,7 @@ def test_frame_from_several_exported_tables_sums_equal_strings():
             for e, reads in ((e1, a), (e2, b), (e3, c)):
                 e.submit(reads)
                 n = e.export_size()
-                buf = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+                buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
                 e.export_to(buf.data_ptr(), buf.numel())
                 keep.append(buf)
                 blobs.append((buf.data_ptr(), n))

@@ -88,7 +88,8 @@ enum Counter : int {        // uint64 counters[] in device memory
     C_DBG1 = 12,            //   trips of their claim/publish loop,
     C_DBG2 = 13,            //   claiming CAS issued,
     C_DBG3 = 14,            //   claiming CAS won
-    C_NUM = 15
+    C_DBG4 = 15,            //   reads counted in a workgroup's key cache (printed with VFIND_DEBUG_CLASSES=1)
+    C_NUM = 16
 };
 constexpr int kTableCounters = 4;       // C_ARENA_TOP..C_KEY_DWORDS are reset with the table
 
@@ -140,9 +141,6 @@ hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t 
                      short2 *spans, BatchLists bl, uint64_t *counters);
 hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n,
                          const short2 *spans, bool skip_translation, Table t);
-hipError_t launch_finish_split(hipStream_t s, const uint32_t *rows, uint64_t n, const short2 *spans, bool skip_translation, Table t,
-                               uint32_t *rec, uint32_t *ovf);            // W = 10: k_keys -> k_count (+ overflow lists)
-uint64_t split_ovf_dwords(uint64_t n);                                    // size of ovf for n reads
 hipError_t launch_generic(hipStream_t s, const uint8_t *bytes, const uint64_t *offs, uint64_t n,
                           const GenericParams &gp, int32_t *starts, int32_t *ends, int32_t *ws,
                           uint64_t ws_stride, uint32_t ws_rows, Table t);

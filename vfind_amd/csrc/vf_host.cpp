@@ -94,12 +94,6 @@ template <typename T> struct PinBuf {
 struct Workspace {               // device scratch of one in-flight batch
     DevBuf<short2> spans;
     DevBuf<uint32_t> listP, listS, listW[4], winW[4], winW2, listF, listN, winN, listR, cnt;
-    DevBuf<uint32_t> rec, ovf;    // two-kernel table stage: key records, overflow list
-    int ensure_split(size_t n) {
-        int rc;
-        if ((rc = rec.ensure(n * 12))) return rc;
-        return ovf.ensure(split_ovf_dwords(n));
-    }
     int ensure(size_t n) {
         int rc;
         uint32_t g, seg;
@@ -113,7 +107,7 @@ struct Workspace {               // device scratch of one in-flight batch
     }
     void release() {
         spans.release(); listP.release(); listS.release(); listF.release(); winW2.release(); cnt.release();
-        listN.release(); winN.release(); listR.release(); rec.release(); ovf.release();
+        listN.release(); winN.release(); listR.release();
         for (int q = 0; q < 4; ++q) { listW[q].release(); winW[q].release(); }
     }
 };
@@ -169,7 +163,6 @@ struct vf_ctx {
     bool fast_ok = false;
     bool filter_on = false;      // Myers pre-DP filter + windowed DP usable for these scores
     bool block_filter = true;    // block filter in front of it (VFIND_BLOCK_FILTER=0 switches it off: A/B runs)
-    bool finish_split = false;   // table stage of 10-dword rows as k_keys -> k_count (VFIND_FINISH_SPLIT)
     uint32_t n_threads = 3, queue_len = 2, batch_reads = 1u << 18;
     ScanParams sp{};
     DpParams dpP{}, dpS{};
@@ -180,19 +173,6 @@ struct vf_ctx {
     uint64_t table_slots = 0, arena_dwords = 0;
     DevBuf<uint4> t_slots; DevBuf<uint64_t> t_counts; DevBuf<uint32_t> t_arena; DevBuf<uint64_t> t_counters;
     DevBuf<unsigned long long> t_chunks;
-    // The spare table: vf_table_clear starts the clear of the table in use and switches to the spare, which the
-    // previous clear left empty - the batches submitted next count at once, beside the clear and beside the table
-    // kernel of the batch before them, instead of queueing behind both (one table: finish -> clear -> finish, the
-    // serial spine of every step of a run of short jobs).  Made at the first clear; VFIND_TABLE_SPARE=0 keeps one table.
-    struct Spare {
-        DevBuf<uint4> slots; DevBuf<uint64_t> counts; DevBuf<uint32_t> arena; DevBuf<uint64_t> counters;
-        DevBuf<unsigned long long> chunks;
-        Table tab{};
-        uint64_t table_slots = 0, arena_dwords = 0;
-        hipEvent_t cleared = nullptr;
-        bool valid = false;
-    } spare;
-    bool spare_on = false;       // measured: two table kernels side by side lose more than the clear costs
     // pipeline
     std::vector<std::unique_ptr<Slot>> slots;
     std::mutex mu;
@@ -342,37 +322,6 @@ static int table_clear_locked(vf_ctx *c, bool all_counters = false) {
     HIP_TRY(hipEventRecord(c->clear_event, c->main_stream));
     return VF_OK;
 }
-// the table in use <-> the spare (buffers, geometry and the event that says "cleared")
-static void table_swap_spare(vf_ctx *c) {
-    vf_ctx::Spare &sp = c->spare;
-    std::swap(c->t_slots, sp.slots); std::swap(c->t_counts, sp.counts); std::swap(c->t_arena, sp.arena);
-    std::swap(c->t_counters, sp.counters); std::swap(c->t_chunks, sp.chunks);
-    std::swap(c->tab, sp.tab);
-    std::swap(c->table_slots, sp.table_slots); std::swap(c->arena_dwords, sp.arena_dwords);
-    std::swap(c->clear_event, sp.cleared);
-}
-// first clear of a context: a second table of the first one's present size, cleared (on the main stream)
-static int table_make_spare(vf_ctx *c) {
-    vf_ctx::Spare &sp = c->spare;
-    int rc;
-    if ((rc = sp.slots.ensure(c->table_slots * 4)) || (rc = sp.counts.ensure(c->table_slots * kXcds)) ||
-        (rc = sp.arena.ensure(c->arena_dwords)) || (rc = sp.counters.ensure(C_NUM)) ||
-        (rc = sp.chunks.ensure((size_t)kChunkRows * kMaxGrid))) {
-        sp.slots.release(); sp.counts.release(); sp.arena.release(); sp.counters.release(); sp.chunks.release();
-        return rc;
-    }
-    if (!sp.cleared) HIP_TRY(hipEventCreateWithFlags(&sp.cleared, hipEventDisableTiming));
-    sp.tab = c->tab;
-    sp.tab.chunk_state = sp.chunks.p; sp.tab.slots = sp.slots.p; sp.tab.counts = sp.counts.p;
-    sp.tab.arena = sp.arena.p; sp.tab.counters = sp.counters.p;
-    sp.table_slots = c->table_slots; sp.arena_dwords = c->arena_dwords;
-    table_swap_spare(c);                                   // clear it through the one function that knows the regions
-    rc = table_clear_locked(c, true);
-    table_swap_spare(c);
-    if (rc) return rc;
-    sp.valid = true;
-    return VF_OK;
-}
 
 extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     if (!p || !out) return fail(VF_EINVAL, "null argument");
@@ -418,8 +367,6 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->main_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->clear_event, hipEventDisableTiming));
     if (const char *e = getenv("VFIND_BLOCK_FILTER")) c->block_filter = atoi(e) != 0;
-    if (const char *e = getenv("VFIND_TABLE_SPARE")) c->spare_on = atoi(e) != 0;
-    if (const char *e = getenv("VFIND_FINISH_SPLIT")) c->finish_split = atoi(e) != 0;
     if (const char *e = getenv("VFIND_RES_LANES")) c->n_res = (uint32_t)std::min(std::max(atoi(e), 1), (int)vf_ctx::kMaxResLanes);
     for (uint32_t i = 0; i < c->n_res; ++i) {
         ResLane &L = c->res[i];
@@ -505,8 +452,6 @@ extern "C" void vf_ctx_destroy(vf_ctx *c) {
     c->exp_refs.release(); c->exp_counts.release(); c->d_part.release();
     vf_comm_release(c);
     c->t_slots.release(); c->t_counts.release(); c->t_arena.release(); c->t_counters.release(); c->t_chunks.release();
-    c->spare.slots.release(); c->spare.counts.release(); c->spare.arena.release(); c->spare.counters.release(); c->spare.chunks.release();
-    if (c->spare.cleared) (void)hipEventDestroy(c->spare.cleared);
     c->d_adapters.release();
     if (c->clear_event) (void)hipEventDestroy(c->clear_event);
     if (c->main_stream) (void)hipStreamDestroy(c->main_stream);
@@ -686,12 +631,7 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
     tab.chunk_row = chunk_row;
     // only the table kernels are ordered after the latest clear; scan and DP may overlap it
     if (count) HIP_TRY(hipStreamWaitEvent(st, c->clear_event, 0));
-    if (count && c->finish_split && W == 10) {
-        int rc = ws.ensure_split(n);
-        if (rc) return rc;
-        Timed t(c, st, K_FIN);
-        HIP_TRY(launch_finish_split(st, d_rows, n, d_spans, c->skip_translation, tab, ws.rec.p, ws.ovf.p));
-    } else if (count) { Timed t(c, st, K_FIN); HIP_TRY(launch_finish(st, W, d_rows, d_lens, n, d_spans, c->skip_translation, tab)); }
+    if (count) { Timed t(c, st, K_FIN); HIP_TRY(launch_finish(st, W, d_rows, d_lens, n, d_spans, c->skip_translation, tab)); }
     // the entry count rides back with the batch: the host grows the table between batches when it fills
     if (count && h_entries) HIP_TRY(hipMemcpyAsync(h_entries, c->t_counters.p + C_ENTRIES, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     return VF_OK;
@@ -1038,12 +978,10 @@ extern "C" int vf_process_device_packed(vf_ctx *c, const void *d_rows, uint32_t 
         HIP_TRY(hipMemcpy(tot, L.ws.cnt.p + 9 * kMaxGrid, sizeof(tot), hipMemcpyDeviceToHost));
         fprintf(stderr, "vfind classes (narrow band, banded, window, long window, two windows, full width): prefix %u %u %u %u %u %u  suffix %u %u %u %u %u %u\n",
                 tot[5], tot[0], tot[1], tot[2], tot[3], tot[4], tot[13], tot[8], tot[9], tot[10], tot[11], tot[12]);
-        if (c->finish_split && W == 10 && L.ws.ovf.p) {
-            std::vector<uint32_t> per(kMaxGrid);
-            HIP_TRY(hipMemcpy(per.data(), L.ws.ovf.p, kMaxGrid * sizeof(uint32_t), hipMemcpyDeviceToHost));
-            uint64_t novf = 0;
-            for (uint32_t v : per) novf += v;           // (workgroups beyond the grid hold stale or no counts: diagnosis only)
-            fprintf(stderr, "vfind table stage: about %llu of %llu reads on the overflow lists (key longer than a record holds)\n", (unsigned long long)novf, (unsigned long long)n);
+        {
+            uint64_t hits = 0;
+            HIP_TRY(hipMemcpy(&hits, c->t_counters.p + C_DBG4, sizeof(hits), hipMemcpyDeviceToHost));
+            if (hits) fprintf(stderr, "vfind table stage: %llu reads counted in a key cache so far (diagnosis build)\n", (unsigned long long)hits);
         }
     }
     return VF_OK;
@@ -1098,17 +1036,10 @@ extern "C" int vf_table_clear(vf_ctx *c) {
         if (s->in_flight) HIP_TRY(hipStreamWaitEvent(c->main_stream, s->done, 0));
     for (auto &L : c->res)
         if (L.in_flight) HIP_TRY(hipStreamWaitEvent(c->main_stream, L.done, 0));
-    std::unique_lock<std::shared_mutex> table_lock(c->table_mu);        // the table in use changes hands below
+    std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
     { std::lock_guard<std::mutex> g(c->cap_mu); c->upper_entries = c->unenqueued; c->upper_arena = c->unenqueued_arena; }
     c->part_world = 0;
-    if (c->spare_on && !c->spare.valid) {
-        int rc = table_make_spare(c);
-        if (rc == VF_ENOMEM) c->spare_on = false;          // no room for a second table: clear in place, as before
-        else if (rc) return rc;
-    }
-    int rc = table_clear_locked(c);
-    if (rc == VF_OK && c->spare.valid) table_swap_spare(c);
-    return rc;
+    return table_clear_locked(c);
 }
 
 static uint64_t blob_bytes(uint64_t n, uint64_t arena_dw) { return 16 + n * 16 + arena_dw * 4; }
@@ -1459,11 +1390,6 @@ extern "C" int vf_stats_get(vf_ctx *c, vf_stats *o) {
     if (rc && rc != VF_ECAPACITY) return rc;
     uint64_t h[C_NUM];
     HIP_TRY(hipMemcpy(h, c->t_counters.p, sizeof(h), hipMemcpyDeviceToHost));
-    if (c->spare.valid) {                                  // read statistics outlive a clear: they sit in both counter arrays
-        uint64_t h2[C_NUM];
-        HIP_TRY(hipMemcpy(h2, c->spare.counters.p, sizeof(h2), hipMemcpyDeviceToHost));
-        for (int k = kTableCounters; k < C_NUM; ++k) h[k] += h2[k];
-    }
     memset(o, 0, sizeof(*o));
     o->reads = c->n_reads; o->reads_generic = c->n_generic;
     o->dp_prefix = h[C_DP_PREFIX]; o->dp_suffix = h[C_DP_SUFFIX];
@@ -1488,11 +1414,6 @@ extern "C" int vf_stats_reset(vf_ctx *c) {
     HIP_TRY(hipMemcpy(c->t_counters.p + C_ACCEPTED, z, 4 * sizeof(uint64_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->t_counters.p + C_SLOW, z, sizeof(uint64_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->t_counters.p + C_DBG0, z, 4 * sizeof(uint64_t), hipMemcpyHostToDevice));
-    if (c->spare.valid) {
-        HIP_TRY(hipMemcpy(c->spare.counters.p + C_ACCEPTED, z, 4 * sizeof(uint64_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(c->spare.counters.p + C_SLOW, z, sizeof(uint64_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(c->spare.counters.p + C_DBG0, z, 4 * sizeof(uint64_t), hipMemcpyHostToDevice));
-    }
     return VF_OK;
 }
 extern "C" int vf_set_profiling(vf_ctx *c, int on) {

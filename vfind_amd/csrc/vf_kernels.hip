@@ -1696,6 +1696,54 @@ __device__ __forceinline__ void agg_flush(Agg &a, const Table &t, uint32_t xcc) 
         if (a.slot[i] != kNoSlot && a.cnt[i]) count_add(t, xcc, a.slot[i], (unsigned long long)a.cnt[i]);
 }
 
+// Workgroup-level key cache: the keys the workgroup has already found in the table, whole, in LDS.  A read whose key sits
+// here is counted without touching the table at all.  What it saves is not HBM traffic (a hot slot line never leaves
+// the XCD's L2) but requests to ONE line: the first key of the Zipf stream is 12 % of the reads, the first ten a third,
+// and every lookup of a key is two or three 16-byte requests to the same L2 line from every CU of the XCD, served one
+// after the other by that line's channel.  Entry = 16 dwords:
+//   { state, h1, h2, meta | slot, count, -, - | key[0..3] | key[4..7] }     state 0 empty, 1 being filled, 2 ready
+// direct mapped by h1; filled by the lane that first finds the key in the table (fast path) while the entry is empty,
+// never replaced; keys of more than eight dwords are not cached.  Flushed like the aggregator at kernel end.
+constexpr int kKeyCacheSize = 512;
+struct KeyCache { u32x4 q[kKeyCacheSize][4]; };
+__device__ __forceinline__ void keycache_init(KeyCache &kc) {
+    for (int i = threadIdx.x; i < kKeyCacheSize; i += kBlock) { kc.q[i][0] = u32x4{0u, 0u, 0u, 0u}; kc.q[i][1] = u32x4{0u, 0u, 0u, 0u}; }
+}
+__device__ __forceinline__ uint32_t keycache_index(uint32_t h1) { return (h1 * 0x9E3779B1u) >> 23; }      // 9 bits
+// true = the key is cached and has been counted there
+__device__ __forceinline__ bool keycache_hit(KeyCache &kc, uint32_t h1, uint32_t h2, uint32_t meta, const uint32_t (&kin)[kInlineDwords], bool can) {
+    if (!can) return false;
+    const uint32_t i = keycache_index(h1);
+    const u32x4 t0 = *(volatile u32x4 *)&kc.q[i][0];
+    if (t0.x != 2u || t0.y != h1 || t0.z != h2 || t0.w != meta) return false;
+    const u32x4 k0 = kc.q[i][2], k1 = kc.q[i][3];
+    const uint32_t diff = (k0.x ^ kin[0]) | (k0.y ^ kin[1]) | (k0.z ^ kin[2]) | (k0.w ^ kin[3]) |
+                          (k1.x ^ kin[4]) | (k1.y ^ kin[5]) | (k1.z ^ kin[6]) | (k1.w ^ kin[7]);
+    if (diff != 0u) return false;
+    atomicAdd(reinterpret_cast<uint32_t *>(&kc.q[i][1]) + 1, 1u);
+    return true;
+}
+// a key just found in the table at `slot` (not yet counted): true = entered into the cache with count 1
+__device__ __forceinline__ bool keycache_fill(KeyCache &kc, uint32_t h1, uint32_t h2, uint32_t meta, const uint32_t (&kin)[kInlineDwords], uint32_t slot) {
+    const uint32_t i = keycache_index(h1);
+    uint32_t *st = reinterpret_cast<uint32_t *>(&kc.q[i][0]);
+    if (*(volatile uint32_t *)st != 0u) return false;
+    if (atomicCAS(st, 0u, 1u) != 0u) return false;
+    kc.q[i][2] = u32x4{kin[0], kin[1], kin[2], kin[3]};
+    kc.q[i][3] = u32x4{kin[4], kin[5], kin[6], kin[7]};
+    kc.q[i][1] = u32x4{slot, 1u, 0u, 0u};
+    st[1] = h1; st[2] = h2; st[3] = meta;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    *(volatile uint32_t *)st = 2u;
+    return true;
+}
+__device__ __forceinline__ void keycache_flush(KeyCache &kc, const Table &t, uint32_t xcc) {
+    for (int i = threadIdx.x; i < kKeyCacheSize; i += kBlock) {
+        const u32x4 t0 = kc.q[i][0], t1 = kc.q[i][1];
+        if (t0.x == 2u && t1.y) count_add(t, xcc, t1.x, (unsigned long long)t1.y);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_finish: extract seq[start..end], translate, count
 // ------------------------------------------------------------------------------------------------
@@ -1797,6 +1845,7 @@ __device__ __forceinline__ void slot_load_key(const uint4 *p, uint32_t nd, bool 
 }
 struct FastProbe {
     uint32_t slot;
+    uint32_t h1, h2, meta;
     uint64_t w0want;
     uint32_t kin[kInlineDwords];
     uint32_t nd;
@@ -1813,6 +1862,7 @@ __device__ __forceinline__ void fast_prepare(const Table &t, const uint32_t (&ke
     hash_fin(h);
     p.can = act && nd <= (uint32_t)kInlineDwords;
     p.nd = nd;
+    p.h1 = h.h1; p.h2 = h.h2; p.meta = meta;
     p.w0want = (uint64_t)h.h2 | ((uint64_t)meta << 32) | kW0Ready;
     p.slot = h.h1 & t.slot_mask;
     rk.head(nd, p.kin);
@@ -1844,46 +1894,41 @@ __device__ __forceinline__ void slot_load2(const uint4 *p, const uint4 *q, uint4
 // lookup are queued per wave in LDS and handled 64 at a time by table_find_or_insert, so the insert
 // protocol's extra round trips are paid by full waves instead of by every wave that holds one new key.
 constexpr int kSlowCap = 192;
-#ifdef VF_FINISH_WPE
-#define VF_FINISH_ATTR __attribute__((amdgpu_flat_work_group_size(kBlock, kBlock), amdgpu_waves_per_eu(VF_FINISH_WPE, VF_FINISH_WPE)))
-#else
-#define VF_FINISH_ATTR __launch_bounds__(kBlock)
+#ifndef VF_KEYCACHE
+#define VF_KEYCACHE 1
 #endif
-// LIST: each workgroup counts the reads of its own index list instead of the grid striding over reads 0..n_reads-1 (the
-// overflow lists of k_keys, same grid); the buffer comes in through the lens argument, which the kernel has no other use
-// for, the capacity of a list through n_reads.
-template <int W, int U, bool DNA, int DBG = 0, bool LIST = false>
+// (register caps through amdgpu_waves_per_eu were tried: 96 registers -> 20 bytes of scratch and +3 % per step, 80 -> 80 bytes
+// and +20 %)
+#define VF_FINISH_ATTR __launch_bounds__(kBlock)
+template <int W, int U, bool DNA, int DBG = 0>
 __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens,
-                                                   uint64_t n_reads_arg, const short2 *__restrict__ spans, Table t) {
-    const uint32_t *lst = reinterpret_cast<const uint32_t *>(lens) + (LIST ? kMaxGrid + (uint64_t)blockIdx.x * n_reads_arg : 0);
-    const uint64_t n_reads = LIST ? (uint64_t)reinterpret_cast<const uint32_t *>(lens)[blockIdx.x] : n_reads_arg;
+                                                   uint64_t n_reads, const short2 *__restrict__ spans, Table t) {
     using FK = FinishKey<W, DNA>;
     constexpr int ND = FK::ND;
     __shared__ uint8_t lut[64];
     __shared__ Agg agg;
+    __shared__ KeyCache kc;
     __shared__ BlockTable bt;
     __shared__ uint32_t s_stat[3];
     __shared__ uint32_t s_slow[kBlock / WAVE][kSlowCap];
     if (threadIdx.x < 64) lut[threadIdx.x] = c_codon_le[threadIdx.x];
     if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
     agg_init(agg);
+    keycache_init(kc);
     block_table_begin(bt, t);
     __syncthreads();
     const uint32_t lane = lane_id();
     const uint32_t xcc = xcc_id();
     uint32_t *slow = s_slow[threadIdx.x / WAVE];
     uint32_t nslow = 0;                           // wave-uniform
-    const uint64_t gstride = LIST ? (uint64_t)kBlock : (uint64_t)gridDim.x * kBlock;
-    const uint64_t tid = LIST ? (uint64_t)threadIdx.x : (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t gstride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint64_t n_trips = (n_reads + gstride * U - 1) / (gstride * U);
 
     short2 sp_next[U];
     uint32_t x_next[U][W + 2];
-    uint32_t id_next[U];                          // LIST: the read the entry names
-    auto prefetch = [&](int u, uint64_t ii) {
-        uint64_t rr = ii;
-        if constexpr (LIST) { id_next[u] = ii < n_reads ? lst[ii] : 0u; rr = id_next[u]; }
-        if (ii < n_reads) {
+    auto prefetch = [&](int u, uint64_t rr) {
+        if (rr < n_reads) {
             sp_next[u] = spans[rr];
             if constexpr (DBG == 2) {
 #pragma unroll
@@ -1906,12 +1951,10 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
             int start[U], end[U];
             bool ok[U];
             uint64_t r[U];
-            uint32_t rid[U];
             bool any_ok = false;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 r[u] = tid + (trip * U + (uint64_t)u) * gstride;
-                if constexpr (LIST) rid[u] = id_next[u];
                 start[u] = sp_next[u].x; end[u] = sp_next[u].y;
                 ok[u] = start[u] >= 0 && end[u] >= 0 && start[u] < end[u];      // lib.rs:288
 #pragma unroll
@@ -1934,7 +1977,15 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
                     n_act += (uint32_t)__popcll(__ballot(act[u]));
                 }
                 if (lane == 0) { atomicAdd(&s_stat[0], n_ok); atomicAdd(&s_stat[1], n_act); }
-                bool found[U];
+                bool found[U], cached[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    cached[u] = VF_KEYCACHE && keycache_hit(kc, fp[u].h1, fp[u].h2, fp[u].meta, fp[u].kin, fp[u].can && fp[u].nd <= 8u);
+                    fp[u].can = fp[u].can && !cached[u];
+#ifdef VF_FINISH_ABLATION
+                    { const uint64_t mh = __ballot(cached[u]); if (mh && lane == 0) atomicAdd((unsigned long long *)&t.counters[C_DBG4], (unsigned long long)__popcll(mh)); }
+#endif
+                }
                 if constexpr (U == 2) {
                     uint4 a, b, c, d, e, f, g, h;
                     if constexpr (DBG == 1 || DBG == 3) { found[0] = fp[0].can; found[1] = fp[1].can; }
@@ -1953,10 +2004,13 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if (found[u] && DBG != 3 && DBG != 4) agg_add(agg, t, xcc, fp[u].slot);
-                    const bool miss = act[u] && !found[u];
+                    if (found[u] && DBG != 3 && DBG != 4) {
+                        const bool entered = VF_KEYCACHE && fp[u].nd <= 8u && keycache_fill(kc, fp[u].h1, fp[u].h2, fp[u].meta, fp[u].kin, fp[u].slot);
+                        if (!entered) agg_add(agg, t, xcc, fp[u].slot);
+                    }
+                    const bool miss = act[u] && !found[u] && !cached[u];
                     const uint64_t m = __ballot(miss);
-                    if (miss) slow[nslow + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = LIST ? rid[u] : (uint32_t)r[u];
+                    if (miss) slow[nslow + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r[u];
                     nslow += (uint32_t)__popcll(m);
                     if (m && lane == 0) atomicAdd(&s_stat[2], (uint32_t)__popcll(m));
                     // capacity: < 64 queued before a trip, at most 64 more per read of the trip
@@ -1988,185 +2042,13 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
     }
     __syncthreads();
     agg_flush(agg, t, xcc);
+    keycache_flush(kc, t, xcc);
     block_table_end(bt, t);
     if (threadIdx.x == 0) {
         if (s_stat[0]) atomicAdd((unsigned long long *)&t.counters[C_ACCEPTED], (unsigned long long)s_stat[0]);
         if (s_stat[1]) atomicAdd((unsigned long long *)&t.counters[C_COUNTED], (unsigned long long)s_stat[1]);
         if (s_stat[2]) atomicAdd((unsigned long long *)&t.counters[C_SLOW], (unsigned long long)s_stat[2]);
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The table stage as two kernels (rows of 10 dwords): k_keys -> k_count
-// ------------------------------------------------------------------------------------------------
-// k_finish is bound by the latency of its table accesses and holds 3 waves x 112 registers of every SIMD while it waits:
-// two thirds of the register file for 0.6 ms, which is what slows the other batch lane's scan / filter / DP waves beside
-// it (chain alone on two lanes: 0.505 ms per step; k_finish alone 0.6; together 0.90).  Split, the part that needs the
-// registers (row, shifter, translation, hash: VALU work, streams) no longer waits on the table, and the part that waits on
-// the table holds a 12-dword record per read and little else.
-//   record of a read (12 dwords): { h1, h2, meta = len | kind << 16, 0, key[0..7] }, meta kRecNone = nothing to count,
-//   kRecOver = key longer than 8 dwords: the read's index goes to the workgroup's overflow list and a k_finish over the
-//   lists counts it (3 % of the reads of the cfg-2 stream).  Overflow buffer: [kMaxGrid] entries per workgroup, then
-//   one list of seg_cap indices per workgroup - a global list behind one counter cost 1.5 ms of same-address atomics.
-constexpr int kRecDwords = 12, kRecKey = 8;
-constexpr uint32_t kRecNone = 0xFFFFFFFFu, kRecOver = 0xFFFFFFFEu;
-
-template <int W, bool DNA>
-__global__ __launch_bounds__(kBlock) void k_keys(const uint32_t *__restrict__ rows, uint64_t n_reads, const short2 *__restrict__ spans,
-                                                 uint32_t *__restrict__ rec, uint32_t *__restrict__ ovf, uint64_t seg_cap,
-                                                 uint64_t *__restrict__ counters) {
-    using FK = FinishKey<W, DNA>;
-    constexpr int ND = FK::ND;
-    __shared__ uint8_t lut[64];
-    __shared__ uint32_t s_stat[3];                // accepted, counted, overflow entries
-    if (threadIdx.x < 64) lut[threadIdx.x] = c_codon_le[threadIdx.x];
-    if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t lane = lane_id();
-    const uint64_t gstride = (uint64_t)gridDim.x * kBlock;
-    const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    const uint64_t n_trips = (n_reads + gstride - 1) / gstride;
-    uint32_t *ovf_list = ovf + kMaxGrid + (uint64_t)blockIdx.x * seg_cap;
-    short2 sp_next;
-    uint32_t x_next[W + 2];
-    auto prefetch = [&](uint64_t rr) {
-        if (rr < n_reads) { sp_next = spans[rr]; load_row<W>(rows, rr, x_next); }
-        else {
-            sp_next = make_short2(kNone, kNone);
-#pragma unroll
-            for (int i = 0; i < W + 2; ++i) x_next[i] = 0;
-        }
-    };
-    prefetch(tid);
-    uint32_t n_ok = 0, n_act = 0;                 // wave-uniform
-    for (uint64_t trip = 0; trip < n_trips; ++trip) {
-        const uint64_t r = tid + trip * gstride;
-        uint32_t x[W + 2];
-        const int start = sp_next.x, end = sp_next.y;
-        const bool ok = start >= 0 && end >= 0 && start < end;            // lib.rs:288
-#pragma unroll
-        for (int i = 0; i < W + 2; ++i) x[i] = x_next[i];
-        prefetch(r + gstride);
-        uint32_t key[ND];
-        uint32_t len = 0;
-        bool act = false;
-        uint32_t meta = kRecNone;
-        Hash h{0u, 0u};
-        if (__any(ok)) {
-            finish_key<W, DNA>(x, start, end, ok, lut, key, len, act);
-            const uint32_t nd = key_dwords(FK::kKind, len);
-            const uint32_t m = len | (FK::kKind << 16);
-            hash_init(h, m);
-            const RegKey<ND> rk{key};
-            rk.each(nd, [&](uint32_t, uint32_t v) { hash_step(h, v); });
-            hash_fin(h);
-            const bool over = act && nd > (uint32_t)kRecKey;
-            meta = !act ? kRecNone : (over ? kRecOver : m);
-            n_ok += (uint32_t)__popcll(__ballot(ok && !over));           // (the overflow pass counts its own reads)
-            n_act += (uint32_t)__popcll(__ballot(act && !over));
-            const uint64_t mo = __ballot(over);
-            if (mo) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&s_stat[2], (uint32_t)__popcll(mo));
-                base = (uint32_t)__shfl((int)base, 0);
-                if (over) ovf_list[base + (uint32_t)__popcll(mo & ((1ull << lane) - 1ull))] = (uint32_t)r;
-            }
-        } else {
-#pragma unroll
-            for (int d = 0; d < ND; ++d) key[d] = 0;
-        }
-        if (r < n_reads) {
-            u32x4 *o = reinterpret_cast<u32x4 *>(rec + r * kRecDwords);
-            o[0] = u32x4{h.h1, h.h2, meta, 0u};
-            o[1] = u32x4{key[0], key[1], key[2], key[3]};
-            o[2] = u32x4{key[4], key[5], key[6], key[7]};
-        }
-    }
-    if (lane == 0) { atomicAdd(&s_stat[0], n_ok); atomicAdd(&s_stat[1], n_act); }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (s_stat[0]) atomicAdd((unsigned long long *)&counters[C_ACCEPTED], (unsigned long long)s_stat[0]);
-        if (s_stat[1]) atomicAdd((unsigned long long *)&counters[C_COUNTED], (unsigned long long)s_stat[1]);
-        ovf[blockIdx.x] = s_stat[2];
-    }
-}
-
-struct Rec { u32x4 a, b, c; };
-__device__ __forceinline__ void rec_load(const uint32_t *rec, uint64_t r, bool in, Rec &o) {
-    if (in) {
-        const u32x4 *p = reinterpret_cast<const u32x4 *>(rec + r * kRecDwords);
-        o.a = p[0]; o.b = p[1]; o.c = p[2];
-    } else {
-        o.a = u32x4{0u, 0u, kRecNone, 0u}; o.b = u32x4{0u, 0u, 0u, 0u}; o.c = o.b;
-    }
-}
-template <bool DNA>
-__global__ __launch_bounds__(kBlock) void k_count(const uint32_t *__restrict__ rec, uint64_t n_reads, Table t) {
-    constexpr uint32_t kKind = DNA ? kKindPacked : kKindBytes;
-    constexpr uint32_t kMaxLen = DNA ? 16u * kRecKey : 4u * kRecKey;       // what eight key dwords hold
-    __shared__ Agg agg;
-    __shared__ BlockTable bt;
-    __shared__ uint32_t s_stat[1];
-    __shared__ uint32_t s_slow[kBlock / WAVE][kSlowCap];
-    if (threadIdx.x < 1) s_stat[threadIdx.x] = 0;
-    agg_init(agg);
-    block_table_begin(bt, t);
-    __syncthreads();
-    const uint32_t lane = lane_id();
-    const uint32_t xcc = xcc_id();
-    uint32_t *slow = s_slow[threadIdx.x / WAVE];
-    uint32_t nslow = 0;                           // wave-uniform
-    const uint64_t gstride = (uint64_t)gridDim.x * kBlock;
-    const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    const uint64_t n_trips = (n_reads + gstride - 1) / gstride;
-    Rec nx;
-    rec_load(rec, tid, tid < n_reads, nx);
-    for (uint64_t trip = 0; trip <= n_trips; ++trip) {
-        const bool last = trip == n_trips;        // the extra trip only drains the slow list
-        if (!last) {
-            const uint64_t r = tid + trip * gstride;
-            const Rec cu = nx;
-            rec_load(rec, r + gstride, r + gstride < n_reads, nx);
-            const uint32_t meta = cu.a.z;
-            const bool act = meta < kRecOver;
-            if (__any(act)) {
-                const uint32_t slot = cu.a.x & t.slot_mask;
-                const uint32_t nd = key_dwords(kKind, min(meta & 0xFFFFu, kMaxLen));
-                const uint64_t w0want = (uint64_t)cu.a.y | ((uint64_t)meta << 32) | kW0Ready;
-                uint4 l0, l1, l2, l3;
-                slot_load_key(t.slots + (uint64_t)slot * 4, nd, act, l0, l1, l2, l3);
-                const uint64_t w0 = (uint64_t)l0.x | ((uint64_t)l0.y << 32);
-                const uint32_t diff = (l0.z ^ cu.b.x) | (l0.w ^ cu.b.y) | (l1.x ^ cu.b.z) | (l1.y ^ cu.b.w) |
-                                      (l1.z ^ cu.c.x) | (l1.w ^ cu.c.y) | (l2.x ^ cu.c.z) | (l2.y ^ cu.c.w);
-                const bool found = act && w0 == w0want && diff == 0u;
-                if (found) agg_add(agg, t, xcc, slot);
-                const bool miss = act && !found;
-                const uint64_t m = __ballot(miss);
-                if (miss) slow[nslow + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
-                nslow += (uint32_t)__popcll(m);
-                if (m && lane == 0) atomicAdd(&s_stat[0], (uint32_t)__popcll(m));
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        while (nslow >= (last ? 1u : (uint32_t)WAVE)) {
-            const uint32_t cnt = nslow < (uint32_t)WAVE ? nslow : (uint32_t)WAVE;
-            const uint32_t base = nslow - cnt;
-            const bool mine = lane < cnt;
-            const uint64_t rr = mine ? (uint64_t)((volatile uint32_t *)slow)[base + lane] : 0ull;
-            Rec q;
-            rec_load(rec, rr, mine, q);
-            const uint32_t ks[kRecKey] = {q.b.x, q.b.y, q.b.z, q.b.w, q.c.x, q.c.y, q.c.z, q.c.w};
-            const uint32_t meta = q.a.z;
-            const bool as = mine && meta < kRecOver;
-            agg_add(agg, t, xcc, table_find_or_insert(t, bt, RegKey<kRecKey>{ks}, kKind, as ? min(meta & 0xFFFFu, kMaxLen) : 0u, as));
-            nslow = base;
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    __syncthreads();
-    agg_flush(agg, t, xcc);
-    block_table_end(bt, t);
-    if (threadIdx.x == 0 && s_stat[0]) atomicAdd((unsigned long long *)&t.counters[C_SLOW], (unsigned long long)s_stat[0]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2780,42 +2662,6 @@ hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint1
     default: return hipErrorInvalidValue;
     }
 #undef VF_FINISH
-    return hipGetLastError();
-}
-
-// the table stage as k_keys -> k_count (+ k_finish over the overflow lists); rows of 10 dwords only.  rec: n * kRecDwords
-// dwords, ovf: split_ovf_dwords(n).
-static int split_keys_per_cu() {
-    static const int v = [] { const char *e = getenv("VFIND_KEYS_BLOCKS_PER_CU"); const int x = e ? atoi(e) : 4; return x >= 1 && x <= 8 ? x : 4; }();
-    return v;
-}
-static uint64_t split_ovf_seg(uint64_t n, int gk) {              // reads one workgroup of k_keys sees at most
-    const uint64_t gstride = (uint64_t)gk * kBlock;
-    return (n + gstride - 1) / gstride * kBlock;
-}
-uint64_t split_ovf_dwords(uint64_t n) {
-    const int gk = grid_for(n, split_keys_per_cu());
-    return (uint64_t)kMaxGrid + (uint64_t)gk * split_ovf_seg(n, gk);
-}
-hipError_t launch_finish_split(hipStream_t s, const uint32_t *rows, uint64_t n, const short2 *spans, bool skip_translation, Table t,
-                               uint32_t *rec, uint32_t *ovf) {
-    if (n == 0) return hipSuccess;
-    if (n >> 32) return hipErrorInvalidValue;
-    hipError_t e = ensure_lut();
-    if (e != hipSuccess) return e;
-    const int keys_per_cu = split_keys_per_cu();
-    static const int count_per_cu = [] { const char *v = getenv("VFIND_COUNT_BLOCKS_PER_CU"); const int x = v ? atoi(v) : 4; return x >= 1 && x <= 8 ? x : 4; }();
-    const int gk = grid_for(n, keys_per_cu), gc = grid_for(n, count_per_cu);
-    const uint64_t seg_cap = split_ovf_seg(n, gk);
-    if (skip_translation) {
-        hipLaunchKernelGGL((k_keys<10, true>), dim3(gk), dim3(kBlock), 0, s, rows, n, spans, rec, ovf, seg_cap, t.counters);
-        hipLaunchKernelGGL((k_count<true>), dim3(gc), dim3(kBlock), 0, s, (const uint32_t *)rec, n, t);
-        hipLaunchKernelGGL((k_finish<10, 1, true, 0, true>), dim3(gk), dim3(kBlock), 0, s, rows, (const uint16_t *)ovf, seg_cap, spans, t);
-    } else {
-        hipLaunchKernelGGL((k_keys<10, false>), dim3(gk), dim3(kBlock), 0, s, rows, n, spans, rec, ovf, seg_cap, t.counters);
-        hipLaunchKernelGGL((k_count<false>), dim3(gc), dim3(kBlock), 0, s, (const uint32_t *)rec, n, t);
-        hipLaunchKernelGGL((k_finish<10, 1, false, 0, true>), dim3(gk), dim3(kBlock), 0, s, rows, (const uint16_t *)ovf, seg_cap, spans, t);
-    }
     return hipGetLastError();
 }
 

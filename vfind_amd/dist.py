@@ -55,21 +55,26 @@ def exchange_shares(engine, group=None, dst: int = 0):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = torch.device("cuda", engine.device)
+    # The library writes and reads these buffers on its own (non-blocking) stream, torch on its current one: a buffer
+    # goes from one to the other only across a device synchronisation, and is allocated without a fill kernel (a
+    # torch.zeros still queued on torch's stream once landed on top of the exported bytes: lost entries on a cold GPU).
     sizes = engine.partition_sizes(world)
     received = []
     for owner in range(world):                                   # round o: everybody's bucket for owner o
-        send = torch.zeros((sizes[owner] + 255) // 256 * 256, dtype=torch.uint8, device=dev)
+        send = torch.empty((sizes[owner] + 255) // 256 * 256, dtype=torch.uint8, device=dev)
         engine.partition_export(world, owner, send.data_ptr(), send.numel())
         parts = allgather_blobs(send, sizes[owner], group)
         if owner == rank:
             received = parts
+    torch.cuda.synchronize(dev)
     engine.clear()
     for buf, nbytes in received:
         engine.merge_from(buf.data_ptr(), nbytes)
     mine = engine.export_size()
-    send = torch.zeros((mine + 255) // 256 * 256, dtype=torch.uint8, device=dev)
+    send = torch.empty((mine + 255) // 256 * 256, dtype=torch.uint8, device=dev)
     engine.export_to(send.data_ptr(), send.numel())
     parts = allgather_blobs(send, mine, group)
+    torch.cuda.synchronize(dev)
     if rank == dst:
         for r, (buf, nbytes) in enumerate(parts):
             if r != rank:
@@ -89,7 +94,7 @@ def allreduce_local(engines, root: int = 0):
         sizes = e.partition_sizes(world)
         row = []
         for owner in range(world):
-            buf = torch.zeros(max(sizes[owner], 16), dtype=torch.uint8, device=torch.device("cuda", e.device))
+            buf = torch.empty(max(sizes[owner], 16), dtype=torch.uint8, device=torch.device("cuda", e.device))
             e.partition_export(world, owner, buf.data_ptr(), buf.numel())
             row.append((buf, sizes[owner]))
         buckets.append(row)
@@ -99,13 +104,17 @@ def allreduce_local(engines, root: int = 0):
         for q in range(world):
             buf, nbytes = buckets[q][o]
             here = buf if buf.device == dev else buf.to(dev)        # kept alive across the (synchronous) merge
+            if here is not buf:
+                torch.cuda.synchronize(dev)                         # the copy ran on torch's stream, the merge will not
             e.merge_from(here.data_ptr(), nbytes)
     for o, e in enumerate(engines):
         if o == root:
             continue
         n = e.export_size()
-        buf = torch.zeros(n + 64, dtype=torch.uint8, device=torch.device("cuda", e.device))
+        buf = torch.empty(n + 64, dtype=torch.uint8, device=torch.device("cuda", e.device))
         e.export_to(buf.data_ptr(), buf.numel())
         rdev = torch.device("cuda", engines[root].device)
         b2 = buf.to(rdev) if buf.device != rdev else buf
+        if b2 is not buf:
+            torch.cuda.synchronize(rdev)
         engines[root].merge_from(b2.data_ptr(), n)
