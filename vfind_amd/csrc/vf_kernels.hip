@@ -1431,6 +1431,11 @@ struct MemKey {
 // (the host sums duplicate strings when it builds the result).  A negative compare is only believed
 // when it comes from a load issued after READY had already been observed.
 constexpr uint64_t kW0Ready = 1ull << 63, kW0Long = 1ull << 50, kW0Ovf = 1ull << 51;
+// kW0One: the entry's count is one more than its count words say - the read that inserted the key left its own count in
+// the claim instead of a count word (an insert then costs no count line: in a cleared table that is one random line read
+// and written back less for every new key, 1.6 M of the 8.7 M random lines of a cfg-2 step).  Set only by the claim, so
+// nothing ever has to change it; every reader of counts adds it (count_of).
+constexpr uint64_t kW0One = 1ull << 52;
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 
 __device__ __forceinline__ void slot_load(const uint4 *p, uint4 &a, uint4 &b, uint4 &c, uint4 &d) {
@@ -1477,6 +1482,9 @@ __device__ __forceinline__ uint64_t count_get(const Table &t, uint64_t slot) {
 #pragma unroll
     for (int x = 0; x < kXcds; ++x) v += t.counts[(uint64_t)x * ((uint64_t)t.slot_mask + 1ull) + slot];
     return v;
+}
+__device__ __forceinline__ uint64_t count_of(const Table &t, uint64_t slot, uint64_t w0) {      // the entry's count (see kW0One)
+    return count_get(t, slot) + ((w0 & kW0One) ? 1ull : 0ull);
 }
 
 // ---- workgroup-local state: arena chunks for LONG keys, insert counters --------------------------
@@ -1530,10 +1538,13 @@ __device__ __forceinline__ int arena_alloc(BlockTable &bt, const Table &t, uint3
 // Finds key's slot, inserting the key if absent; returns kNoSlot on a capacity error.
 // have_off: arena offset the (LONG) key already occupies (table growth re-inserts entries whose keys stay where they
 // are), kNoOff = the key is copied into a fresh arena allocation.
+// one: the caller is counting ONE occurrence; if this lane is the one that inserts the key, the claim carries that count
+// (kW0One) and `counted` comes back true - the caller then adds nothing.
 constexpr uint64_t kNoOff = ~0ull;
 template <class K>
 __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTable &bt, const K &key, uint32_t kind, uint32_t len, bool active,
-                                                         uint64_t have_off = kNoOff) {
+                                                         uint64_t have_off, bool one, bool &counted) {
+    counted = false;
     uint32_t found = kNoSlot;
     const uint32_t nd = key_dwords(kind, len);
     const uint32_t meta = len | (kind << 16);
@@ -1543,12 +1554,13 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
     hash_fin(h);
     const bool is_long = nd > (uint32_t)kInlineDwords;
     const uint64_t w0mine = (uint64_t)h.h2 | ((uint64_t)meta << 32) | (is_long ? kW0Long : 0ull);
+    const uint64_t w0pub = w0mine | (one ? kW0One : 0ull);                // what this lane writes if it inserts
     // Letter keys (kind 0) validate themselves: every dword of a written key is non-zero, so a slot can
     // be claimed READY at once and its key stored without waiting; a reader that meets a zero dword
     // inside the key's length knows the line is still in flight and looks again.  Packed-DNA keys may
     // hold zero dwords and keep the claim -> store -> wait -> READY order.
     const bool selfval = kind == kKindBytes && !is_long;
-    const uint64_t w0claim = selfval ? (w0mine | kW0Ready) : w0mine;
+    const uint64_t w0claim = selfval ? (w0pub | kW0Ready) : w0pub;
     uint32_t kin[kInlineDwords];
     key.head(nd, kin);
     uint32_t slot = h.h1 & t.slot_mask;
@@ -1592,15 +1604,17 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
                     atomicAdd(&bt.new_entries, 1u);
                     atomicAdd(&bt.new_key_dwords, nd);
                     found = slot;
+                    counted = one;
                     done = true;
                 } else if (!is_long) {
                     // the line is ours (w0 claimed, READY clear): rewrite it whole, then publish
-                    slot_store(sp, u32x4{(uint32_t)w0mine, (uint32_t)(w0mine >> 32), kin[0], kin[1]}, u32x4{kin[2], kin[3], kin[4], kin[5]},
+                    slot_store(sp, u32x4{(uint32_t)w0pub, (uint32_t)(w0pub >> 32), kin[0], kin[1]}, u32x4{kin[2], kin[3], kin[4], kin[5]},
                                u32x4{kin[6], kin[7], kin[8], kin[9]}, u32x4{kin[10], kin[11], kin[12], kin[13]});
-                    st_agent(reinterpret_cast<unsigned long long *>(sp), (unsigned long long)(w0mine | kW0Ready));
+                    st_agent(reinterpret_cast<unsigned long long *>(sp), (unsigned long long)(w0pub | kW0Ready));
                     atomicAdd(&bt.new_entries, 1u);
                     atomicAdd(&bt.new_key_dwords, nd);
                     found = slot;
+                    counted = one;
                     done = true;
                 } else {
                     uint64_t off = have_off;
@@ -1609,10 +1623,11 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
                         if (have_off == kNoOff) key.each(nd, [&](uint32_t d, uint32_t v) { st_agent(&t.arena[off + d], v); });
                         st_agent(kw, (unsigned long long)off);
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        st_agent(reinterpret_cast<unsigned long long *>(sp), (unsigned long long)(w0mine | kW0Ready));
+                        st_agent(reinterpret_cast<unsigned long long *>(sp), (unsigned long long)(w0pub | kW0Ready));
                         atomicAdd(&bt.new_entries, 1u);
                         atomicAdd(&bt.new_key_dwords, nd);
                         found = slot;
+                        counted = one;
                         done = true;
                     } else if (rc == kAllocFull) {
                         atomicOr((unsigned long long *)&t.counters[C_ERROR], 1ull);
@@ -1620,7 +1635,7 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
                         done = true;
                     }
                 }
-            } else if ((w0 & ~(kW0Ready | kW0Ovf)) == w0mine) {
+            } else if ((w0 & ~(kW0Ready | kW0Ovf | kW0One)) == w0mine) {
                 if (!(w0 & kW0Ready)) {
                     // claimed by another lane, key not yet published: look at the same slot again next trip
                 } else if (w0 & kW0Ovf) {
@@ -1666,8 +1681,10 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
 template <class K>
 __device__ __forceinline__ void table_add(const Table &t, BlockTable &bt, const K &key, uint32_t kind, uint32_t len, uint64_t cnt, bool active,
                                           uint64_t have_off = kNoOff) {
-    const uint32_t slot = table_find_or_insert(t, bt, key, kind, len, active, have_off);
-    if (slot != kNoSlot) count_add(t, xcc_id(), slot, (unsigned long long)cnt);
+    bool counted;
+    const bool one = cnt == 1ull;
+    const uint32_t slot = table_find_or_insert(t, bt, key, kind, len, active, have_off, one, counted);
+    if (slot != kNoSlot && !counted) count_add(t, xcc_id(), slot, (unsigned long long)cnt);
 }
 
 // Workgroup-level count aggregation: a small LDS table keyed by slot index collects the +1s of a
@@ -1872,7 +1889,7 @@ __device__ __forceinline__ bool fast_check(const FastProbe &p, const uint4 &l0, 
     const uint32_t diff = (l0.z ^ p.kin[0]) | (l0.w ^ p.kin[1]) | (l1.x ^ p.kin[2]) | (l1.y ^ p.kin[3]) | (l1.z ^ p.kin[4]) | (l1.w ^ p.kin[5]) |
                           (l2.x ^ p.kin[6]) | (l2.y ^ p.kin[7]) | (l2.z ^ p.kin[8]) | (l2.w ^ p.kin[9]) | (l3.x ^ p.kin[10]) | (l3.y ^ p.kin[11]) |
                           (l3.z ^ p.kin[12]) | (l3.w ^ p.kin[13]);
-    return p.can && w0 == p.w0want && diff == 0u;
+    return p.can && (w0 & ~kW0One) == p.w0want && diff == 0u;
 }
 // two independent slot lines in flight at once
 __device__ __forceinline__ void slot_load2(const uint4 *p, const uint4 *q, uint4 &a, uint4 &b, uint4 &c, uint4 &d,
@@ -2035,7 +2052,9 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
             uint32_t ls;
             bool as;
             finish_key<W, DNA>(xs, sp.x, sp.y, oks, lut, ks, ls, as);
-            agg_add(agg, t, xcc, table_find_or_insert(t, bt, RegKey<ND>{ks}, FK::kKind, ls, as));
+            bool counted;
+            const uint32_t sl = table_find_or_insert(t, bt, RegKey<ND>{ks}, FK::kKind, ls, as, kNoOff, true, counted);
+            if (!counted) agg_add(agg, t, xcc, sl);
             nslow = base;
             __builtin_amdgcn_wave_barrier();
         }
@@ -2431,7 +2450,7 @@ __global__ __launch_bounds__(kBlock) void k_export(Table t, uint64_t *__restrict
             const uint64_t e = base_e + __popcll(m & ((1ull << lane_id()) - 1ull));
             const uint64_t ko = base_k + (incl - nd);
             out_refs[e] = (ko << 24) | kRefValid | (uint64_t)meta;
-            out_counts[e] = count_get(t, s);
+            out_counts[e] = count_of(t, s, w0);
             if (w0 & kW0Long) {
                 const uint64_t off = (uint64_t)l0.z | ((uint64_t)l0.w << 32);
                 for (uint32_t d = 0; d < nd; ++d) out_arena[ko + d] = t.arena[off + d];
@@ -2480,7 +2499,7 @@ __global__ __launch_bounds__(kBlock) void k_rehash(Table from, Table to) {
             w0 = (uint64_t)l0.x | ((uint64_t)l0.y << 32);
             live = (w0 & kW0Ready) && !(w0 & kW0Ovf);
             if (live) {
-                cnt = count_get(from, s);
+                cnt = count_of(from, s, w0);
                 off = (uint64_t)l0.z | ((uint64_t)l0.w << 32);
                 kp = (w0 & kW0Long) ? from.arena + off : reinterpret_cast<const uint32_t *>(sp) + 2;
             }
