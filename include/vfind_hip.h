@@ -166,7 +166,9 @@ struct ArrowArray {
 int vf_result_export_arrow(vf_result *r, struct ArrowArray *out_array, struct ArrowSchema *out_schema);
 
 /* Empties the device count table (a new find_variants call on a reused context).  Asynchronous:
- * ordered after every batch already submitted and before everything submitted afterwards. */
+ * ordered after every batch already submitted and before everything submitted afterwards.  From the first call on the
+ * context owns a second table of the same size: the call hands the empty one to the batches that follow and clears the
+ * used one beside them (VFIND_TABLE_SPARE=0 in the environment: one table, cleared in place). */
 int vf_table_clear(vf_ctx *ctx);
 
 /* Multi-GPU exchange of the (key,count) table (the reduce of lib.rs:292-306 across GPUs).

@@ -479,6 +479,53 @@ def test_table_export_merge_and_clear():
         assert e1.finish_dict() == oracle.count(b, AD20)
 
 
+def test_clear_switches_to_the_spare_table():
+    """vf_table_clear hands the next batches an empty second table and clears the used one beside them: round after round
+    the counts are those of that round's reads alone, the table grows on whichever side it fills, the read statistics
+    carry across the switch, and a clear with batches still in flight drops them"""
+    from vfind_amd import Engine
+    rounds = [synth.make_reads(300 + i, 9000, AD20, L=150, n_variants=3000 + 500 * i, sub=0.003, indel=0.0) for i in range(5)]
+    with Engine(AD20, table_slots=1 << 10, arena_bytes=1 << 22, batch_reads=1500, queue_len=3) as e:
+        counted = 0
+        for i, reads in enumerate(rounds):
+            if i == 3:
+                e.submit(rounds[0])             # still in flight when the clear comes: never seen again
+                counted += sum(oracle.count(rounds[0], AD20).values())
+            e.clear()
+            e.submit(reads)
+            want = oracle.count(reads, AD20)
+            assert e.finish_dict() == want, f"round {i}"
+            counted += sum(want.values())
+            assert e.stats()["counted"] == counted
+        e.clear()
+        assert e.finish_dict() == {}
+    # resident-batch lanes (the bench's path) through the same switch: every step a cleared table, two lanes in flight
+    import torch
+    from benchlib import synth as vsynth
+    gen = vsynth.Generator(0xBEEF, AD20, n_variants=5000)
+    n = 60000
+    wins = []
+    for w in range(3):
+        rows, lens = gen.packed(w * n, n, 4)
+        data, offs = gen.ascii(w * n, n, 4)
+        wins.append((torch.from_numpy(rows).cuda(), torch.from_numpy(lens.view("int16")).cuda(), rows.shape[1],
+                     oracle.count((data, offs), AD20, n_threads=4)))
+    with Engine(AD20, table_slots=1 << 16) as e:            # (a resident batch must fit the table it meets)
+        for w in (0, 1, 2, 1, 0, 2):
+            dr, dl, W, want = wins[w]
+            e.clear()
+            e.process_device(dr.data_ptr(), W, dl.data_ptr(), n)
+        assert e.finish_dict() == wins[2][3]                # only the last step's reads are in the table
+        e.clear()
+        for w in (0, 1):                                    # no clear in between: both batches in one table
+            dr, dl, W, want = wins[w]
+            e.process_device(dr.data_ptr(), W, dl.data_ptr(), n)
+        both = dict(wins[0][3])
+        for k, v in wins[1][3].items():
+            both[k] = both.get(k, 0) + v
+        assert e.finish_dict() == both
+
+
 def test_table_grows_between_batches():
     """a table that fills up is quadrupled and re-hashed on the device between batches"""
     from vfind_amd import Engine
