@@ -1692,7 +1692,10 @@ __device__ __forceinline__ void table_add(const Table &t, BlockTable &bt, const 
 // head of the variant distribution costs one global atomic per workgroup instead of one per read
 // (same-address global atomics serialise at ~10 ns each).  Slots that lose the LDS entry to another
 // slot fall through to a direct global atomic.
-constexpr int kAggSize = 1024;
+#ifndef VF_AGG_SIZE
+#define VF_AGG_SIZE 1024
+#endif
+constexpr int kAggSize = VF_AGG_SIZE;
 struct Agg {
     uint32_t slot[kAggSize];
     uint32_t cnt[kAggSize];
@@ -1702,7 +1705,7 @@ __device__ __forceinline__ void agg_init(Agg &a) {
 }
 __device__ __forceinline__ void agg_add(Agg &a, const Table &t, uint32_t xcc, uint32_t slot) {
     if (slot == kNoSlot) return;
-    const uint32_t i = (slot * 0x9E3779B1u) >> 22;                 // 10 bits
+    const uint32_t i = ((slot * 0x9E3779B1u) >> 16) & (uint32_t)(kAggSize - 1);
     uint32_t cur = *(volatile uint32_t *)&a.slot[i];
     if (cur == kNoSlot) { cur = atomicCAS(&a.slot[i], kNoSlot, slot); if (cur == kNoSlot) cur = slot; }
     if (cur == slot) atomicAdd(&a.cnt[i], 1u);
@@ -1721,12 +1724,15 @@ __device__ __forceinline__ void agg_flush(Agg &a, const Table &t, uint32_t xcc) 
 //   { state, h1, h2, meta | slot, count, -, - | key[0..3] | key[4..7] }     state 0 empty, 1 being filled, 2 ready
 // direct mapped by h1; filled by the lane that first finds the key in the table (fast path) while the entry is empty,
 // never replaced; keys of more than eight dwords are not cached.  Flushed like the aggregator at kernel end.
-constexpr int kKeyCacheSize = 512;
+#ifndef VF_KEYCACHE_SIZE
+#define VF_KEYCACHE_SIZE 256
+#endif
+constexpr int kKeyCacheSize = VF_KEYCACHE_SIZE;        // power of two
 struct KeyCache { u32x4 q[kKeyCacheSize][4]; };
 __device__ __forceinline__ void keycache_init(KeyCache &kc) {
     for (int i = threadIdx.x; i < kKeyCacheSize; i += kBlock) { kc.q[i][0] = u32x4{0u, 0u, 0u, 0u}; kc.q[i][1] = u32x4{0u, 0u, 0u, 0u}; }
 }
-__device__ __forceinline__ uint32_t keycache_index(uint32_t h1) { return (h1 * 0x9E3779B1u) >> 23; }      // 9 bits
+__device__ __forceinline__ uint32_t keycache_index(uint32_t h1) { return ((h1 * 0x9E3779B1u) >> 16) & (uint32_t)(kKeyCacheSize - 1); }
 // true = the key is cached and has been counted there
 __device__ __forceinline__ bool keycache_hit(KeyCache &kc, uint32_t h1, uint32_t h2, uint32_t meta, const uint32_t (&kin)[kInlineDwords], bool can) {
     if (!can) return false;
