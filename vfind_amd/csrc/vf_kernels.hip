@@ -1920,8 +1920,8 @@ constexpr int kSlowCap = 192;
 #ifndef VF_KEYCACHE
 #define VF_KEYCACHE 1
 #endif
-// (register caps through amdgpu_waves_per_eu were tried: 96 registers -> 20 bytes of scratch and +3 % per step, 80 -> 80 bytes
-// and +20 %)
+// (register caps through amdgpu_waves_per_eu were tried: 96 registers -> 32 bytes of scratch, two of its reloads on the path of
+// every trip: k_finish +15 %, k_scan beside it -8 % with its third wave per SIMD, the step +2 %; 80 registers -> +20 %)
 #define VF_FINISH_ATTR __launch_bounds__(kBlock)
 template <int W, int U, bool DNA, int DBG = 0>
 __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens,
@@ -2761,7 +2761,8 @@ extern "C" int vf_debug_dp_trace(uint64_t *out) {          // diagnosis build: 2
 hipError_t launch_clear(hipStream_t s, const ClearRegions &cr) {
     for (int q = 0; q < 4; ++q)
         if (((uintptr_t)cr.p[q] & 15u) || (cr.bytes[q] & 3u)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_clear, dim3(2048), dim3(kBlock), 0, s, cr);
+    static const int grid = [] { const char *v = getenv("VFIND_CLEAR_GRID"); const int x = v ? atoi(v) : 2048; return x >= 1 && x <= (int)kMaxGrid ? x : 2048; }();
+    hipLaunchKernelGGL(k_clear, dim3(grid), dim3(kBlock), 0, s, cr);
     return hipGetLastError();
 }
 
