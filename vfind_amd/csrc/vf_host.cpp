@@ -1095,13 +1095,18 @@ extern "C" int vf_table_clear(vf_ctx *c) {
     std::unique_lock<std::shared_mutex> table_lock(c->table_mu);        // the table in use changes hands below
     { std::lock_guard<std::mutex> g(c->cap_mu); c->upper_entries = c->unenqueued; c->upper_arena = c->unenqueued_arena; }
     c->part_world = 0;
-    if (c->spare_on && !c->spare.valid) {
+    // The switch pays while the clear is small beside a batch: 2^21 slots (268 MB to zero) -3 % per step of cfg 2; 2^25 slots
+    // (4.3 GB, the cfg-5 shape at 10 M reads a step) +8 % - that clear is better off alone on the stream than beside
+    // the kernels of the next batch for a whole millisecond.
+    constexpr uint64_t kSpareMaxSlots = 1ull << 22;
+    const bool small = c->table_slots <= kSpareMaxSlots && (!c->spare.valid || c->spare.table_slots <= kSpareMaxSlots);
+    if (c->spare_on && small && !c->spare.valid) {
         int rc = table_make_spare(c);
         if (rc == VF_ENOMEM) c->spare_on = false;          // no room for a second table: clear in place, as before
         else if (rc) return rc;
     }
     int rc = table_clear_locked(c);
-    if (rc == VF_OK && c->spare.valid) table_swap_spare(c);
+    if (rc == VF_OK && c->spare.valid && small) table_swap_spare(c);
     return rc;
 }
 
