@@ -443,7 +443,7 @@ def main():
             "cpu_baseline": cpu,
             "parity_gate": parity, "parity_full_size": parity_full, "table_cleared_each_step": not keep_table,
             "merge_ms": None if merge_ms is None else round(merge_ms, 3), "merge_error": merge_error,
-            "merge_transport": None if world == 1 else (("rccl (vf_table_allreduce)" if args.backend == "nccl" else "torch") if args.merge_transport == "auto" else args.merge_transport),
+            "merge_transport": None if world == 1 else {"rccl": "rccl (vf_table_allreduce)"}.get(getattr(eng, "last_merge_transport", args.merge_transport), getattr(eng, "last_merge_transport", args.merge_transport)),
             "finish": extras.get("finish"), "pcie_inclusive": extras.get("pcie_inclusive"), "end_to_end": extras.get("end_to_end"),
             "tie_sensitive_frac": tie, "valu_util": valu_util_from_profiles(),
             "per_step": {"dp_prefix_tasks": st["dp_prefix"] // steps, "dp_suffix_tasks": st["dp_suffix"] // steps, "insert_path_reads": st["insert_path"] // steps,

@@ -278,18 +278,47 @@ class Engine:
         rank = dist.get_rank(group)
         if world == 1:
             return 0.0
-        if transport == "auto":
+        auto = transport == "auto"
+        if auto:
             transport = "rccl" if dist.get_backend(group) == "nccl" else "torch"
         dev = torch.device("cuda", self.device)
+        wire = dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
         t0 = time.perf_counter()
+        self.last_merge_transport = transport
         if transport == "rccl":
             if not getattr(self, "_comm_ready", False):
-                uid = torch.zeros(128, dtype=torch.uint8, device=dev if dist.get_backend(group) == "nccl" else "cpu")
-                if rank == 0:
-                    uid.copy_(torch.frombuffer(bytearray(self.comm_unique_id()), dtype=torch.uint8))
-                dist.broadcast(uid, src=0, group=group)
-                self.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
-                self._comm_ready = True
+                # the communicator first, and every rank hears whether every rank got one: with "auto" a rank that
+                # cannot bring RCCL up through the library (no librccl.so.1, an init error) sends everybody to the torch
+                # transport before any table has been touched, instead of leaving its peers inside a collective
+                err = None
+                my_id = None
+                try:
+                    my_id = self.comm_unique_id()                  # also the probe: loads librccl.so.1 on this rank
+                except Exception as e:                            # noqa: BLE001 - agreed on below
+                    err = e
+                can = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=wire)
+                dist.all_reduce(can, op=dist.ReduceOp.MIN, group=group)
+                if int(can.item()) == 1:                          # every rank has the library: the collective init is safe to enter
+                    uid = torch.zeros(128, dtype=torch.uint8, device=wire)
+                    if rank == 0:
+                        uid.copy_(torch.frombuffer(bytearray(my_id), dtype=torch.uint8))
+                    dist.broadcast(uid, src=0, group=group)
+                    try:
+                        self.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+                    except Exception as e:                        # noqa: BLE001
+                        err = e
+                elif err is None:
+                    err = VfindError("a peer cannot load RCCL through the library")
+                ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=wire)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+                if int(ok.item()) == 0:
+                    if not auto:
+                        raise err if err is not None else VfindError("a peer could not initialise RCCL through the library")
+                    transport = "torch"
+                    self.last_merge_transport = f"torch (rccl unavailable{': ' + str(err) if err is not None else ' on a peer'})"
+                else:
+                    self._comm_ready = True
+        if transport == "rccl":
             self.allreduce_rccl(dst)
         else:
             exchange_shares(self, group, dst)
