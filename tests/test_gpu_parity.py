@@ -526,6 +526,60 @@ def test_clear_switches_to_the_spare_table():
         assert e.finish_dict() == both
 
 
+def test_count_words_fold_into_base_counts():
+    """the per-XCD count words are 32 bits wide; the host folds them into the 64-bit base counts before the reads counted since
+    the last fold could carry one over.  With the bound lowered to 20 000 reads (VFIND_FOLD_LIMIT, a test hook) every other
+    batch forces a fold - streaming submits, resident batches, a merge and a table growth in between - and the counts stay
+    those of the oracle"""
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    code = r'''
+import numpy as np, torch, vfind_amd
+from oracle import oracle
+from tests import synth
+from benchlib import synth as vsynth
+AD = ("ACGTTGCAAGCTTGCATGCA", "TTGACCGTAAGCTAGGCTAA")
+reads = synth.make_reads(77, 60000, AD, L=150, n_variants=4000, sub=0.003, indel=0.0)
+want = oracle.count(reads, AD)
+with vfind_amd.Engine(AD, table_slots=1 << 10, arena_bytes=1 << 22, batch_reads=4000, queue_len=3) as e, vfind_amd.Engine(AD) as e2:
+    for lo in range(0, len(reads), 6000):
+        e.submit(reads[lo:lo + 6000])
+    assert e.finish_dict() == want
+    e2.submit(reads[:30000])
+    n = e2.export_size()
+    buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    e2.export_to(buf.data_ptr(), n + 64)
+    e.merge_from(buf.data_ptr(), n)
+    e.submit(reads[:6000])
+    both = dict(want)
+    for k, v in oracle.count(reads[:30000], AD).items():
+        both[k] = both.get(k, 0) + v
+    for k, v in oracle.count(reads[:6000], AD).items():
+        both[k] = both.get(k, 0) + v
+    assert e.finish_dict() == both
+gen = vsynth.Generator(0xF01D, AD, n_variants=3000)
+n = 30000
+with vfind_amd.Engine(AD, table_slots=1 << 15) as e:
+    tot = {}
+    for w in range(4):
+        rows, lens = gen.packed(w * n, n, 4)
+        data, offs = gen.ascii(w * n, n, 4)
+        dr, dl = torch.from_numpy(rows).cuda(), torch.from_numpy(lens.view("int16")).cuda()
+        e.process_device(dr.data_ptr(), rows.shape[1], dl.data_ptr(), n)
+        e.sync()
+        for k, v in oracle.count((data, offs), AD, n_threads=4).items():
+            tot[k] = tot.get(k, 0) + v
+    assert e.finish_dict() == tot
+print("ok")
+'''
+    env = dict(os.environ, VFIND_FOLD_LIMIT="20000", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "ok" in out.stdout
+    assert out.stderr.count("count words folded") >= 6, out.stderr[-2000:]
+
+
 def test_table_grows_between_batches():
     """a table that fills up is quadrupled and re-hashed on the device between batches"""
     from vfind_amd import Engine

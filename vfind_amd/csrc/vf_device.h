@@ -94,6 +94,7 @@ enum Counter : int {        // uint64 counters[] in device memory
 constexpr int kTableCounters = 4;       // C_ARENA_TOP..C_KEY_DWORDS are reset with the table
 
 constexpr int kXcds = 8;                // MI355X: 8 XCDs, each with its own L2 (count arrays are per XCD)
+constexpr int kCountWords = kXcds + 2;  // dwords of count storage per slot: kXcds 32-bit words and one 64-bit base count
 constexpr uint32_t kChunk = 1024;       // dwords of key arena a workgroup takes per refill (arena_alloc)
 constexpr uint32_t kChunkRows = 21;     // chunk-state rows: 16 batch streams, the main stream, 4 resident lanes
 
@@ -101,7 +102,8 @@ struct Table {
     unsigned long long *chunk_state;  // [kChunkRows][kMaxGrid] workgroup arena chunks (see arena_alloc)
     uint32_t chunk_row;               // row of the launching stream
     uint4 *slots;                     // 4 x uint4 per slot
-    uint64_t *counts;                 // [kXcds][slots]: one count per slot and XCD, apart from the slot lines
+    uint32_t *counts;                 // [kXcds][slots] 32-bit counts, one per slot and XCD, apart from the slot lines; then
+                                      // [slots] 64-bit base counts (count_base): kCountWords dwords per slot in all
     uint32_t *arena;                  // long keys only
     uint64_t *counters;
     uint32_t slot_mask;
@@ -151,6 +153,7 @@ hipError_t launch_line_index(hipStream_t s, const uint8_t *text, uint64_t n, uin
 hipError_t launch_frame_pack(hipStream_t s, int W, const uint8_t *text, const uint32_t *line_end, uint32_t n_rec, uint32_t *rows,
                              uint16_t *lens, uint32_t *gen_start, uint32_t *gen_len, uint32_t *info, bool all_generic);
 struct ClearRegions { void *p[4]; uint64_t bytes[4]; };   // 16-byte aligned starts, sizes multiples of 4
+hipError_t launch_fold(hipStream_t s, Table t);          // per-XCD 32-bit counts -> 64-bit base counts, words zeroed
 hipError_t launch_clear(hipStream_t s, const ClearRegions &cr);
 // G = 0: the whole table; otherwise the entries owned by `owner` of G in the multi-GPU exchange
 hipError_t launch_export(hipStream_t s, Table t, uint64_t *out_refs, uint64_t *out_counts, uint32_t *out_arena, uint32_t G, uint32_t owner);

@@ -171,7 +171,7 @@ struct vf_ctx {
     // table
     Table tab{};
     uint64_t table_slots = 0, arena_dwords = 0;
-    DevBuf<uint4> t_slots; DevBuf<uint64_t> t_counts; DevBuf<uint32_t> t_arena; DevBuf<uint64_t> t_counters;
+    DevBuf<uint4> t_slots; DevBuf<uint32_t> t_counts; DevBuf<uint32_t> t_arena; DevBuf<uint64_t> t_counters;
     DevBuf<unsigned long long> t_chunks;
     // The spare table: vf_table_clear starts the clear of the table in use and switches to the spare, which the
     // previous clear left empty - the batches submitted next count at once, beside the clear, instead of queueing behind
@@ -180,7 +180,7 @@ struct vf_ctx {
     // longer each and the step gets slower, one after the other with the clear beside them it gets 3 % faster.
     // Made at the first clear (a context that is never cleared never pays for it); VFIND_TABLE_SPARE=0 keeps one table.
     struct Spare {
-        DevBuf<uint4> slots; DevBuf<uint64_t> counts; DevBuf<uint32_t> arena; DevBuf<uint64_t> counters;
+        DevBuf<uint4> slots; DevBuf<uint32_t> counts; DevBuf<uint32_t> arena; DevBuf<uint64_t> counters;
         DevBuf<unsigned long long> chunks;
         Table tab{};
         uint64_t table_slots = 0, arena_dwords = 0;
@@ -196,6 +196,10 @@ struct vf_ctx {
     hipStream_t main_stream = nullptr;
     hipEvent_t clear_event = nullptr;   // recorded on main_stream after each table clear
     hipEvent_t fin_event = nullptr;     // spare table: recorded after each table kernel, the next one waits for it (one at a time)
+    // 32-bit count words (vf_kernels.hip, count_add): occurrences handed to the device since the words were last folded into
+    // the 64-bit base counts; a fold comes before they could reach 2^32 (VFIND_FOLD_LIMIT lowers the bound: tests)
+    std::mutex fold_mu;
+    uint64_t since_fold = 0, fold_limit = 1ull << 31, folds = 0;
     bool fin_recorded = false;
     static constexpr int kMaxResLanes = 4;
     ResLane res[kMaxResLanes];   // vf_process_device_packed: batch k+1's scan/DP overlaps batch k's finish
@@ -331,7 +335,7 @@ static int table_clear_locked(vf_ctx *c, bool all_counters = false) {
     // arena top, entry count and error bits belong to the table; the read statistics do not
     ClearRegions cr;
     cr.p[0] = c->t_slots.p;    cr.bytes[0] = c->table_slots * 64;
-    cr.p[1] = c->t_counts.p;   cr.bytes[1] = c->table_slots * kXcds * sizeof(uint64_t);
+    cr.p[1] = c->t_counts.p;   cr.bytes[1] = c->table_slots * kCountWords * sizeof(uint32_t);
     cr.p[2] = c->t_chunks.p;   cr.bytes[2] = (uint64_t)kChunkRows * kMaxGrid * sizeof(unsigned long long);
     cr.p[3] = c->t_counters.p; cr.bytes[3] = (all_counters ? (uint64_t)C_NUM : (uint64_t)kTableCounters) * sizeof(uint64_t);
     HIP_TRY(launch_clear(c->main_stream, cr));
@@ -352,7 +356,7 @@ static void table_swap_spare(vf_ctx *c) {
 static int table_make_spare(vf_ctx *c) {
     vf_ctx::Spare &sp = c->spare;
     int rc;
-    if ((rc = sp.slots.ensure(c->table_slots * 4)) || (rc = sp.counts.ensure(c->table_slots * kXcds)) ||
+    if ((rc = sp.slots.ensure(c->table_slots * 4)) || (rc = sp.counts.ensure(c->table_slots * kCountWords)) ||
         (rc = sp.arena.ensure(c->arena_dwords)) || (rc = sp.counters.ensure(C_NUM)) ||
         (rc = sp.chunks.ensure((size_t)kChunkRows * kMaxGrid))) {
         sp.slots.release(); sp.counts.release(); sp.arena.release(); sp.counters.release(); sp.chunks.release();
@@ -417,6 +421,7 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     HIP_TRY(hipEventCreateWithFlags(&c->fin_event, hipEventDisableTiming));
     if (const char *e = getenv("VFIND_BLOCK_FILTER")) c->block_filter = atoi(e) != 0;
     if (const char *e = getenv("VFIND_TABLE_SPARE")) c->spare_on = atoi(e) != 0;
+    if (const char *e = getenv("VFIND_FOLD_LIMIT")) { const uint64_t v = strtoull(e, nullptr, 0); if (v >= 1 && v <= (1ull << 31)) c->fold_limit = v; }
     if (const char *e = getenv("VFIND_RES_LANES")) c->n_res = (uint32_t)std::min(std::max(atoi(e), 1), (int)vf_ctx::kMaxResLanes);
     for (uint32_t i = 0; i < c->n_res; ++i) {
         ResLane &L = c->res[i];
@@ -453,7 +458,7 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     // count table
     c->arena_dwords = (p->arena_bytes ? p->arena_bytes : (1ull << 30)) / 4;
     if ((rc = c->t_slots.ensure(c->table_slots * 4))) return rc;
-    if ((rc = c->t_counts.ensure(c->table_slots * kXcds))) return rc;
+    if ((rc = c->t_counts.ensure(c->table_slots * kCountWords))) return rc;
     if ((rc = c->t_arena.ensure(c->arena_dwords))) return rc;
     if ((rc = c->t_counters.ensure(C_NUM))) return rc;
     if ((rc = c->t_chunks.ensure((size_t)kChunkRows * kMaxGrid))) return rc;
@@ -585,11 +590,11 @@ static int table_grow_locked(vf_ctx *c, bool use_unenqueued, uint64_t extra, uin
     while ((h[C_ENTRIES] + extra) * 2 > c->table_slots) {
         const uint64_t new_slots = c->table_slots * 4;
         if (new_slots > (1ull << 32)) return fail(VF_ECAPACITY, "device count table cannot grow beyond 2^32 slots");
-        DevBuf<uint4> n_slots; DevBuf<uint64_t> n_counts;
+        DevBuf<uint4> n_slots; DevBuf<uint32_t> n_counts;
         if ((rc = n_slots.ensure(new_slots * 4))) return rc;
-        if ((rc = n_counts.ensure(new_slots * kXcds))) { n_slots.release(); return rc; }
+        if ((rc = n_counts.ensure(new_slots * kCountWords))) { n_slots.release(); return rc; }
         HIP_TRY(hipMemsetAsync(n_slots.p, 0, new_slots * 64, c->main_stream));
-        HIP_TRY(hipMemsetAsync(n_counts.p, 0, new_slots * kXcds * sizeof(uint64_t), c->main_stream));
+        HIP_TRY(hipMemsetAsync(n_counts.p, 0, new_slots * kCountWords * sizeof(uint32_t), c->main_stream));
         HIP_TRY(hipMemsetAsync(c->t_counters.p + C_ENTRIES, 0, sizeof(uint64_t), c->main_stream));     // recounted by the re-insert
         HIP_TRY(hipMemsetAsync(c->t_counters.p + C_KEY_DWORDS, 0, sizeof(uint64_t), c->main_stream));
         Table to = c->tab;
@@ -614,6 +619,28 @@ static int table_grow_if_needed(vf_ctx *c, uint64_t entries_hint) {
     return table_grow_locked(c, false, 0);
 }
 
+// Called (without the table lock) before `add` more occurrences are handed to the device: a count word is 32 bits wide and
+// holds what its XCD counted for one key since the last fold, at most everything handed over since then.  The bound is
+// 2^31: what other threads have noted but not yet enqueued when a fold happens lands after it without being counted again
+// here - a few batches, far from the other 2^31.  A single batch beyond the bound (the resident path takes up to 2^32 - 16
+// reads) gets a fold before it and one before whatever follows it.  The fold excludes every submitter (table lock) and
+// waits for the device: it happens once per 2^31 reads.
+static int counts_note(vf_ctx *c, uint64_t add) {
+    std::lock_guard<std::mutex> g(c->fold_mu);
+    if (c->since_fold + add <= c->fold_limit) { c->since_fold += add; return VF_OK; }
+    if (c->since_fold != 0) {
+        std::unique_lock<std::shared_mutex> lk(c->table_mu);
+        int rc;
+        if ((rc = sync_all_streams(c))) return rc;
+        HIP_TRY(launch_fold(c->main_stream, c->tab));
+        HIP_TRY(hipStreamSynchronize(c->main_stream));
+        ++c->folds;
+        if (c->fold_limit != (1ull << 31)) fprintf(stderr, "vfind: count words folded into the base counts (%llu)\n", (unsigned long long)c->folds);   // test hook only
+    }
+    c->since_fold = add;
+    return VF_OK;
+}
+
 // streaming paths: every read of a batch may add a key, so a batch is only enqueued when the table
 // could take all of them (a conservative count, refreshed from the device whenever it runs out)
 struct CapacityTicket {
@@ -629,6 +656,8 @@ static inline uint64_t arena_need(const vf_ctx *c, uint32_t len) {
     return nd > kChunk / 4 ? nd + kChunk : nd + nd / 3 + 1;
 }
 static int reserve_capacity(vf_ctx *c, CapacityTicket &t, uint64_t n, uint64_t arena) {
+    int frc = counts_note(c, n);
+    if (frc) return frc;
     uint64_t up, upa;
     {
         std::lock_guard<std::mutex> g(c->cap_mu);
@@ -1019,6 +1048,7 @@ extern "C" int vf_process_device_packed(vf_ctx *c, const void *d_rows, uint32_t 
     if (L.in_flight && hipEventQuery(L.done) == hipSuccess) {           // lane idle: its entry count is current
         if ((rc = table_grow_if_needed(c, *L.h_entries.p))) return rc;
     }
+    if ((rc = counts_note(c, n))) return rc;
     std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
     if ((rc = L.ws.ensure(n))) return rc;
     short2 *spans = d_spans ? (short2 *)d_spans : L.ws.spans.p;
@@ -1092,8 +1122,10 @@ extern "C" int vf_table_clear(vf_ctx *c) {
         if (s->in_flight) HIP_TRY(hipStreamWaitEvent(c->main_stream, s->done, 0));
     for (auto &L : c->res)
         if (L.in_flight) HIP_TRY(hipStreamWaitEvent(c->main_stream, L.done, 0));
+    std::lock_guard<std::mutex> fold_lock(c->fold_mu);                  // (lock order: fold_mu, then the table lock - counts_note)
     std::unique_lock<std::shared_mutex> table_lock(c->table_mu);        // the table in use changes hands below
     { std::lock_guard<std::mutex> g(c->cap_mu); c->upper_entries = c->unenqueued; c->upper_arena = c->unenqueued_arena; }
+    c->since_fold = 0;                                                  // the table handed out next has empty count words
     c->part_world = 0;
     // The switch pays while the clear is small beside a batch: 2^21 slots (268 MB to zero) -3 % per step of cfg 2; 2^25 slots
     // (4.3 GB, the cfg-5 shape at 10 M reads a step) +8 % - that clear is better off alone on the stream than beside
@@ -1207,6 +1239,7 @@ extern "C" int vf_table_merge(vf_ctx *c, const void *d_blob, uint64_t nbytes) {
         std::lock_guard<std::mutex> g(c->cap_mu);
         c->upper_entries += hdr[0]; c->upper_arena += hdr[1];
     }
+    if ((rc = counts_note(c, hdr[0]))) return rc;      // (an entry of count 1 is one more in a 32-bit count word)
     std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
     c->part_world = 0;
     const uint8_t *b = (const uint8_t *)d_blob;

@@ -1464,7 +1464,10 @@ __device__ __forceinline__ void slot_store_nowait(uint4 *p, u32x4 a, u32x4 b, u3
                  "global_store_dwordx4 %0, %4, off offset:48 sc1"
                  :: "v"(p), "v"(a), "v"(b), "v"(c), "v"(d) : "memory");
 }
-// Counts: one u64 array per XCD (t.counts[xcd][slot]).  A count is bumped with an atomic that executes in
+// The count words are 32 bits wide (half the count lines to clear, to keep in the caches and to write back; -3 % per
+// step of cfg 2): the host folds them into the 64-bit base counts (k_fold) before the reads counted since the last fold
+// could carry one over (vf_host.cpp, counts_note), and counts of any size (merge, growth) go to the base count directly.
+// Counts: one array per XCD (t.counts[xcd][slot]).  A count is bumped with an atomic that executes in
 // the issuing XCD's own L2 (no sc1): all CUs of an XCD share that L2, and no other XCD ever touches this
 // copy, so the add is coherent without going to the memory side - device-scope atomics do, and ~3 M of
 // them per 10 M reads cost more than everything else in k_finish together (measured: 0.45 ms of 0.55).
@@ -1473,12 +1476,19 @@ __device__ __forceinline__ uint32_t xcc_id() {
     // HW_REG_XCC_ID (id 20), bits [3:0]: s_getreg_b32 simm16 = (size-1)<<11 | offset<<6 | id
     return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & (uint32_t)(kXcds - 1);
 }
-__device__ __forceinline__ void count_add(const Table &t, uint32_t xcc, uint32_t slot, unsigned long long v) {
-    unsigned long long *p = reinterpret_cast<unsigned long long *>(t.counts) + (uint64_t)xcc * ((uint64_t)t.slot_mask + 1ull) + slot;
+__device__ __forceinline__ void count_add(const Table &t, uint32_t xcc, uint32_t slot, uint32_t v) {
+    uint32_t *p = t.counts + (uint64_t)xcc * ((uint64_t)t.slot_mask + 1ull) + slot;
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+__device__ __forceinline__ unsigned long long *count_base(const Table &t) {
+    return reinterpret_cast<unsigned long long *>(t.counts + (uint64_t)kXcds * ((uint64_t)t.slot_mask + 1ull));
+}
+// a count of any size, from any XCD (device scope: slow, and only merge / growth use it)
+__device__ __forceinline__ void base_add(const Table &t, uint32_t slot, unsigned long long v) {
+    __hip_atomic_fetch_add(count_base(t) + slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ uint64_t count_get(const Table &t, uint64_t slot) {
-    uint64_t v = 0;
+    uint64_t v = count_base(t)[slot];
 #pragma unroll
     for (int x = 0; x < kXcds; ++x) v += t.counts[(uint64_t)x * ((uint64_t)t.slot_mask + 1ull) + slot];
     return v;
@@ -1684,7 +1694,10 @@ __device__ __forceinline__ void table_add(const Table &t, BlockTable &bt, const 
     bool counted;
     const bool one = cnt == 1ull;
     const uint32_t slot = table_find_or_insert(t, bt, key, kind, len, active, have_off, one, counted);
-    if (slot != kNoSlot && !counted) count_add(t, xcc_id(), slot, (unsigned long long)cnt);
+    if (slot != kNoSlot && !counted) {
+        if (one) count_add(t, xcc_id(), slot, 1u);
+        else base_add(t, slot, (unsigned long long)cnt);
+    }
 }
 
 // Workgroup-level count aggregation: a small LDS table keyed by slot index collects the +1s of a
@@ -1709,11 +1722,11 @@ __device__ __forceinline__ void agg_add(Agg &a, const Table &t, uint32_t xcc, ui
     uint32_t cur = *(volatile uint32_t *)&a.slot[i];
     if (cur == kNoSlot) { cur = atomicCAS(&a.slot[i], kNoSlot, slot); if (cur == kNoSlot) cur = slot; }
     if (cur == slot) atomicAdd(&a.cnt[i], 1u);
-    else count_add(t, xcc, slot, 1ull);
+    else count_add(t, xcc, slot, 1u);
 }
 __device__ __forceinline__ void agg_flush(Agg &a, const Table &t, uint32_t xcc) {
     for (int i = threadIdx.x; i < kAggSize; i += kBlock)
-        if (a.slot[i] != kNoSlot && a.cnt[i]) count_add(t, xcc, a.slot[i], (unsigned long long)a.cnt[i]);
+        if (a.slot[i] != kNoSlot && a.cnt[i]) count_add(t, xcc, a.slot[i], a.cnt[i]);
 }
 
 // Workgroup-level key cache: the keys the workgroup has already found in the table, whole, in LDS.  A read whose key sits
@@ -1763,7 +1776,7 @@ __device__ __forceinline__ bool keycache_fill(KeyCache &kc, uint32_t h1, uint32_
 __device__ __forceinline__ void keycache_flush(KeyCache &kc, const Table &t, uint32_t xcc) {
     for (int i = threadIdx.x; i < kKeyCacheSize; i += kBlock) {
         const u32x4 t0 = kc.q[i][0], t1 = kc.q[i][1];
-        if (t0.x == 2u && t1.y) count_add(t, xcc, t1.x, (unsigned long long)t1.y);
+        if (t0.x == 2u && t1.y) count_add(t, xcc, t1.x, t1.y);
     }
 }
 
@@ -2757,6 +2770,26 @@ extern "C" int vf_debug_dp_trace(uint64_t *out) {          // diagnosis build: 2
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dp_trace), sizeof(uint64_t) * 2 * kMaxGrid * 4) == hipSuccess ? 0 : 4;
 }
 #endif
+
+// the 32-bit count words of every slot into its base count (see count_add); nothing else may touch the table meanwhile
+__global__ __launch_bounds__(kBlock) void k_fold(Table t) {
+    const uint64_t nslots = (uint64_t)t.slot_mask + 1;
+    unsigned long long *base = count_base(t);
+    for (uint64_t s = (uint64_t)blockIdx.x * kBlock + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * kBlock) {
+        uint64_t v = 0;
+#pragma unroll
+        for (int x = 0; x < kXcds; ++x) {
+            uint32_t *p = t.counts + (uint64_t)x * nslots + s;
+            const uint32_t w = *p;
+            if (w) { v += w; *p = 0u; }
+        }
+        if (v) base[s] += v;
+    }
+}
+hipError_t launch_fold(hipStream_t s, Table t) {
+    hipLaunchKernelGGL(k_fold, dim3(grid_for((uint64_t)t.slot_mask + 1, 8)), dim3(kBlock), 0, s, t);
+    return hipGetLastError();
+}
 
 hipError_t launch_clear(hipStream_t s, const ClearRegions &cr) {
     for (int q = 0; q < 4; ++q)
