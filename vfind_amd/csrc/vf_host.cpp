@@ -1126,6 +1126,8 @@ extern "C" int vf_table_clear(vf_ctx *c) {
     std::unique_lock<std::shared_mutex> table_lock(c->table_mu);        // the table in use changes hands below
     { std::lock_guard<std::mutex> g(c->cap_mu); c->upper_entries = c->unenqueued; c->upper_arena = c->unenqueued_arena; }
     c->since_fold = 0;                                                  // the table handed out next has empty count words
+    for (auto &s : c->slots) if (s->h_entries.p) *s->h_entries.p = 0;  // (growth hints of the table being dropped)
+    for (auto &L : c->res) if (L.h_entries.p) *L.h_entries.p = 0;
     c->part_world = 0;
     // The switch pays while the clear is small beside a batch: 2^21 slots (268 MB to zero) -3 % per step of cfg 2; 2^25 slots
     // (4.3 GB, the cfg-5 shape at 10 M reads a step) +8 % - that clear is better off alone on the stream than beside
