@@ -396,10 +396,12 @@ def main():
             "dp_window": (st_k["ms_dp_window"], st_k["launches_dp_window"], tasks * (row_b + 14), k_steps),
             "dp_rest": (st_k["ms_dp_rest"], st_k["launches_dp_rest"], tasks * (row_b + 14), k_steps),
             "finish": (st["ms_finish"], st["launches_finish"], n * 4 + st["accepted"] / steps * (row_b + 2), steps),   # timed region
+            # the batch's count log applied to the table (k_log_scatter + k_log_apply, or k_log_direct): one bracket around both
+            "count_log": (st_k.get("ms_count_log", 0.0), st_k.get("launches_count_log", 0), st["counted"] / steps * 4, k_steps),
         }
         # dominant kernel = most device time among the kinds that are one kernel per launch (dp_rest brackets the
         # second window class and the side stream's group of kernels, not a single kernel)
-        dom = max((k for k in kern if k != "dp_rest"), key=lambda k: kern[k][0] / kern[k][3])
+        dom = max((k for k in kern if k not in ("dp_rest", "count_log")), key=lambda k: kern[k][0] / kern[k][3])
         ms_tot, launches, bytes_per_launch, _ = kern[dom]
         avg_ms = ms_tot / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0

@@ -84,6 +84,8 @@ typedef struct vf_stats {
     double ms_result_build;    /* wall time of the latest vf_finish: table export, device dedupe + sort, copy of the frame */
     uint64_t result_rows;      /* rows of that frame */
     uint64_t dbg[4];           /* diagnosis build only (insert-path batches, loop trips, CAS issued, CAS won); 0 in the product */
+    double ms_count_log;       /* device time of the kernels that apply a batch's count log to the table (profiling on) */
+    uint64_t launches_count_log;
 } vf_stats;
 
 const char *vf_last_error(void);

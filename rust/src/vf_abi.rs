@@ -39,6 +39,7 @@ pub struct VfStats {
     pub launches_scan: u64, pub launches_filter: u64, pub launches_dp_window: u64, pub launches_dp_rest: u64, pub launches_finish: u64,
     pub launches_generic: u64, pub insert_path: u64, pub arena_top: u64,
     pub ms_result_build: f64, pub result_rows: u64, pub dbg: [u64; 4],
+    pub ms_count_log: f64, pub launches_count_log: u64,
 }
 
 extern "C" {

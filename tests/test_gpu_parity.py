@@ -526,11 +526,11 @@ def test_clear_switches_to_the_spare_table():
         assert e.finish_dict() == both
 
 
-def test_count_words_fold_into_base_counts():
-    """the per-XCD count words are 32 bits wide; the host folds them into the 64-bit base counts before the reads counted since
-    the last fold could carry one over.  With the bound lowered to 20 000 reads (VFIND_FOLD_LIMIT, a test hook) every other
-    batch forces a fold - streaming submits, resident batches, a merge and a table growth in between - and the counts stay
-    those of the oracle"""
+def test_count_log_both_modes_follow_the_oracle():
+    """k_finish writes occurrences of known keys to the batch's count log; the log is applied by slot ranges (k_log_scatter +
+    k_log_apply) or, for tables far larger than a batch, entry by entry (k_log_direct).  Both forced in turn (VFIND_COUNT_LOG,
+    an A/B switch) over streaming submits, resident batches, a merge and table growth in between: the counts are the
+    oracle's either way"""
     import subprocess
     import sys
     from tests.conftest import ROOT
@@ -573,11 +573,11 @@ with vfind_amd.Engine(AD, table_slots=1 << 15) as e:
     assert e.finish_dict() == tot
 print("ok")
 '''
-    env = dict(os.environ, VFIND_FOLD_LIMIT="20000", PYTHONPATH=ROOT)
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
-    assert "ok" in out.stdout
-    assert out.stderr.count("count words folded") >= 6, out.stderr[-2000:]
+    for mode in ("1", "2"):
+        env = dict(os.environ, VFIND_COUNT_LOG=mode, PYTHONPATH=ROOT)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert out.returncode == 0, (mode, out.stderr[-3000:])
+        assert "ok" in out.stdout
 
 
 def test_table_grows_between_batches():

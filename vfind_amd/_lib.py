@@ -35,7 +35,8 @@ class VfStats(C.Structure):
         "reads", "reads_generic", "dp_prefix", "dp_suffix", "accepted", "counted", "table_entries", "arena_dwords")] + [
         (n, C.c_double) for n in ("ms_scan", "ms_filter", "ms_dp_window", "ms_dp_rest", "ms_finish", "ms_generic")] + [
         (n, C.c_uint64) for n in ("launches_scan", "launches_filter", "launches_dp_window", "launches_dp_rest", "launches_finish", "launches_generic",
-                                  "insert_path", "arena_top")] + [("ms_result_build", C.c_double), ("result_rows", C.c_uint64)] + [(f"dbg{k}", C.c_uint64) for k in range(4)]
+                                  "insert_path", "arena_top")] + [("ms_result_build", C.c_double), ("result_rows", C.c_uint64)] + [(f"dbg{k}", C.c_uint64) for k in range(4)] + [
+        ("ms_count_log", C.c_double), ("launches_count_log", C.c_uint64)]
 
 
 # every symbol include/vfind_hip.h declares: (name, restype, argtypes)

@@ -93,8 +93,7 @@ enum Counter : int {        // uint64 counters[] in device memory
 };
 constexpr int kTableCounters = 4;       // C_ARENA_TOP..C_KEY_DWORDS are reset with the table
 
-constexpr int kXcds = 8;                // MI355X: 8 XCDs, each with its own L2 (count arrays are per XCD)
-constexpr int kCountWords = kXcds + 2;  // dwords of count storage per slot: kXcds 32-bit words and one 64-bit base count
+constexpr int kCountWords = 2;          // dwords of count storage per slot: one 64-bit count, apart from the slot line
 constexpr uint32_t kChunk = 1024;       // dwords of key arena a workgroup takes per refill (arena_alloc)
 constexpr uint32_t kChunkRows = 21;     // chunk-state rows: 16 batch streams, the main stream, 4 resident lanes
 
@@ -102,13 +101,41 @@ struct Table {
     unsigned long long *chunk_state;  // [kChunkRows][kMaxGrid] workgroup arena chunks (see arena_alloc)
     uint32_t chunk_row;               // row of the launching stream
     uint4 *slots;                     // 4 x uint4 per slot
-    uint32_t *counts;                 // [kXcds][slots] 32-bit counts, one per slot and XCD, apart from the slot lines; then
-                                      // [slots] 64-bit base counts (count_base): kCountWords dwords per slot in all
+    unsigned long long *counts;       // [slots] 64-bit counts, apart from the slot lines (only k_log_apply / k_log_direct and the
+                                      // rare count-carrying inserts of merge, growth and the byte-wise path write them)
     uint32_t *arena;                  // long keys only
     uint64_t *counters;
     uint32_t slot_mask;
     uint64_t arena_cap;               // dwords
 };
+
+// ---- deferred count log (one per in-flight batch) ----------------------------------------------
+// k_finish never touches a count: an occurrence of a key that is already in the table is written down as the key's slot
+// index and applied after the kernel (lib.rs:292-306: `*entry += 1` for every read, here once per batch and slot range).
+//   one[wave][cap_one]      slot indices, one occurrence each, appended by the wave with coalesced stores
+//   many[block][kLogMany]   (slot, count) pairs: what the workgroup's LDS aggregator and key cache hold at kernel end
+//   tot[2][kLogMaxParts]    entries per slot part (slot >> shift), written by k_finish, read by scatter and apply
+//   cur[2][kLogMaxParts]    scatter cursors
+// k_log_scatter groups the entries by part (counting sort: totals -> part starts, a run per workgroup and part reserved
+// with one atomic), k_log_apply gives every range of kLogRange slots to one workgroup, which counts its part's entries
+// in LDS and adds what it has to the 64-bit counts, contiguous, once.  parts == 0: k_log_direct adds entry by entry
+// (tables so large that a batch touches few of their ranges).
+constexpr uint32_t kLogMany = 1024 + 256;   // pairs a workgroup can leave: aggregator + key cache entries (vf_kernels.hip)
+constexpr uint32_t kLogMaxParts = 256;
+constexpr uint32_t kLogRange = 8192;        // slots per workgroup of k_log_apply (32 KiB of LDS counters)
+struct CountLog {
+    uint32_t *one, *n_one;
+    uint2 *many;
+    uint32_t *n_many;
+    uint32_t *tot, *cur;
+    uint32_t *one_by_part;            // scatter output, same sizes as one / many
+    uint2 *many_by_part;
+    uint64_t cap_total;               // entries `one` / `one_by_part` can hold
+    uint32_t cap_one;                 // per wave segment
+    uint32_t parts, shift;            // parts == 0: direct mode
+    uint32_t grid;                    // workgroups of the k_finish launch that wrote the log
+};
+uint64_t count_log_entries(uint64_t n_reads, uint32_t *grid, uint32_t *cap_one);   // geometry of launch_finish for n reads
 
 // ---- launchers (vf_kernels.hip) ---------------------------------------------------------------
 struct BatchLists {        // per in-flight batch; lists are segmented per workgroup of k_scan
@@ -141,8 +168,10 @@ hipError_t launch_dp_classes(hipStream_t s, int W, const uint32_t *rows, const u
                              short2 *spans, BatchLists bl, uint64_t *counters);
 hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
                      short2 *spans, BatchLists bl, uint64_t *counters);
+// k_finish, then the kernels that apply its count log (same n, same table, same log, same stream)
 hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n,
-                         const short2 *spans, bool skip_translation, Table t);
+                         const short2 *spans, bool skip_translation, Table t, CountLog log);
+hipError_t launch_count_log(hipStream_t s, uint64_t n, Table t, CountLog log);
 hipError_t launch_generic(hipStream_t s, const uint8_t *bytes, const uint64_t *offs, uint64_t n,
                           const GenericParams &gp, int32_t *starts, int32_t *ends, int32_t *ws,
                           uint64_t ws_stride, uint32_t ws_rows, Table t);
@@ -153,7 +182,6 @@ hipError_t launch_line_index(hipStream_t s, const uint8_t *text, uint64_t n, uin
 hipError_t launch_frame_pack(hipStream_t s, int W, const uint8_t *text, const uint32_t *line_end, uint32_t n_rec, uint32_t *rows,
                              uint16_t *lens, uint32_t *gen_start, uint32_t *gen_len, uint32_t *info, bool all_generic);
 struct ClearRegions { void *p[4]; uint64_t bytes[4]; };   // 16-byte aligned starts, sizes multiples of 4
-hipError_t launch_fold(hipStream_t s, Table t);          // per-XCD 32-bit counts -> 64-bit base counts, words zeroed
 hipError_t launch_clear(hipStream_t s, const ClearRegions &cr);
 // G = 0: the whole table; otherwise the entries owned by `owner` of G in the multi-GPU exchange
 hipError_t launch_export(hipStream_t s, Table t, uint64_t *out_refs, uint64_t *out_counts, uint32_t *out_arena, uint32_t G, uint32_t owner);

@@ -60,7 +60,7 @@ static inline uint32_t base_code(unsigned char ch) { return ch == 'A' ? 0u : ch 
 namespace {
 
 struct EventPair { hipEvent_t a, b; int kind; };
-enum { K_SCAN = 0, K_FILTER, K_DPW, K_DPREST, K_FIN, K_GEN, K_KINDS };
+enum { K_SCAN = 0, K_FILTER, K_DPW, K_DPREST, K_FIN, K_GEN, K_LOG, K_KINDS };
 
 template <typename T> struct DevBuf {
     T *p = nullptr;
@@ -94,6 +94,41 @@ template <typename T> struct PinBuf {
 struct Workspace {               // device scratch of one in-flight batch
     DevBuf<short2> spans;
     DevBuf<uint32_t> listP, listS, listW[4], winW[4], winW2, listF, listN, winN, listR, cnt;
+    // count log of the batch's k_finish (CountLog, vf_device.h)
+    DevBuf<uint32_t> log_one, log_one_by_part, log_n;     // log_n: n_one[kMaxGrid * 4], n_many[kMaxGrid], tot[2][parts], cur[2][parts]
+    DevBuf<uint2> log_many, log_many_by_part;
+    // The log is applied on the context's main stream, off the batch's own: log_written (batch stream, behind k_finish) ->
+    // main stream: scatter, apply, part totals zeroed again -> log_applied, which the next k_finish over this workspace
+    // waits for.  Nothing in a batch's chain of kernels waits for the counts of the batch before it.
+    hipEvent_t log_written = nullptr, log_applied = nullptr;
+    bool log_pending = false;                             // log_applied has been recorded and not yet waited for
+    // main: the stream the log is applied on (it also zeroes a new totals array: k_finish adds to it)
+    int ensure_log(size_t n, hipStream_t main) {
+        int rc;
+        uint32_t g, cap_one;
+        const uint64_t e = count_log_entries(n, &g, &cap_one);
+        if ((rc = log_one.ensure(e)) || (rc = log_one_by_part.ensure(e))) return rc;
+        if ((rc = log_many.ensure((size_t)g * kLogMany)) || (rc = log_many_by_part.ensure((size_t)g * kLogMany))) return rc;
+        if (!log_written && hipEventCreateWithFlags(&log_written, hipEventDisableTiming) != hipSuccess) return fail(VF_EDEVICE, "hipEventCreate failed");
+        if (!log_applied && hipEventCreateWithFlags(&log_applied, hipEventDisableTiming) != hipSuccess) return fail(VF_EDEVICE, "hipEventCreate failed");
+        if (!log_n.p) {
+            if ((rc = log_n.ensure(5 * (size_t)kMaxGrid + 4 * (size_t)kLogMaxParts))) return rc;
+            // (on the main stream and behind an event: a hipMemset on the null stream does not order with these non-blocking
+            // streams and once landed on top of a first batch's entry counts)
+            if (hipMemsetAsync(log_n.p, 0, log_n.cap * sizeof(uint32_t), main) != hipSuccess || hipEventRecord(log_applied, main) != hipSuccess)
+                return fail(VF_EDEVICE, "hipMemsetAsync failed");
+            log_pending = true;
+        }
+        return VF_OK;
+    }
+    CountLog count_log() const {
+        CountLog l{};
+        l.one = log_one.p; l.one_by_part = log_one_by_part.p; l.many = log_many.p; l.many_by_part = log_many_by_part.p;
+        l.n_one = log_n.p; l.n_many = log_n.p + 4 * (size_t)kMaxGrid;
+        l.tot = log_n.p + 5 * (size_t)kMaxGrid; l.cur = l.tot + 2 * (size_t)kLogMaxParts;
+        l.cap_total = log_one.cap;
+        return l;
+    }
     int ensure(size_t n) {
         int rc;
         uint32_t g, seg;
@@ -108,6 +143,10 @@ struct Workspace {               // device scratch of one in-flight batch
     void release() {
         spans.release(); listP.release(); listS.release(); listF.release(); winW2.release(); cnt.release();
         listN.release(); winN.release(); listR.release();
+        log_one.release(); log_one_by_part.release(); log_n.release(); log_many.release(); log_many_by_part.release();
+        if (log_written) (void)hipEventDestroy(log_written);
+        if (log_applied) (void)hipEventDestroy(log_applied);
+        log_written = log_applied = nullptr; log_pending = false;
         for (int q = 0; q < 4; ++q) { listW[q].release(); winW[q].release(); }
     }
 };
@@ -171,7 +210,7 @@ struct vf_ctx {
     // table
     Table tab{};
     uint64_t table_slots = 0, arena_dwords = 0;
-    DevBuf<uint4> t_slots; DevBuf<uint32_t> t_counts; DevBuf<uint32_t> t_arena; DevBuf<uint64_t> t_counters;
+    DevBuf<uint4> t_slots; DevBuf<unsigned long long> t_counts; DevBuf<uint32_t> t_arena; DevBuf<uint64_t> t_counters;
     DevBuf<unsigned long long> t_chunks;
     // The spare table: vf_table_clear starts the clear of the table in use and switches to the spare, which the
     // previous clear left empty - the batches submitted next count at once, beside the clear, instead of queueing behind
@@ -180,7 +219,7 @@ struct vf_ctx {
     // longer each and the step gets slower, one after the other with the clear beside them it gets 3 % faster.
     // Made at the first clear (a context that is never cleared never pays for it); VFIND_TABLE_SPARE=0 keeps one table.
     struct Spare {
-        DevBuf<uint4> slots; DevBuf<uint32_t> counts; DevBuf<uint32_t> arena; DevBuf<uint64_t> counters;
+        DevBuf<uint4> slots; DevBuf<unsigned long long> counts; DevBuf<uint32_t> arena; DevBuf<uint64_t> counters;
         DevBuf<unsigned long long> chunks;
         Table tab{};
         uint64_t table_slots = 0, arena_dwords = 0;
@@ -196,10 +235,7 @@ struct vf_ctx {
     hipStream_t main_stream = nullptr;
     hipEvent_t clear_event = nullptr;   // recorded on main_stream after each table clear
     hipEvent_t fin_event = nullptr;     // spare table: recorded after each table kernel, the next one waits for it (one at a time)
-    // 32-bit count words (vf_kernels.hip, count_add): occurrences handed to the device since the words were last folded into
-    // the 64-bit base counts; a fold comes before they could reach 2^32 (VFIND_FOLD_LIMIT lowers the bound: tests)
-    std::mutex fold_mu;
-    uint64_t since_fold = 0, fold_limit = 1ull << 31, folds = 0;
+    std::mutex log_mu;                  // a batch's count log is applied on the main stream (run_packed)
     bool fin_recorded = false;
     static constexpr int kMaxResLanes = 4;
     ResLane res[kMaxResLanes];   // vf_process_device_packed: batch k+1's scan/DP overlaps batch k's finish
@@ -335,7 +371,7 @@ static int table_clear_locked(vf_ctx *c, bool all_counters = false) {
     // arena top, entry count and error bits belong to the table; the read statistics do not
     ClearRegions cr;
     cr.p[0] = c->t_slots.p;    cr.bytes[0] = c->table_slots * 64;
-    cr.p[1] = c->t_counts.p;   cr.bytes[1] = c->table_slots * kCountWords * sizeof(uint32_t);
+    cr.p[1] = c->t_counts.p;   cr.bytes[1] = c->table_slots * sizeof(unsigned long long);
     cr.p[2] = c->t_chunks.p;   cr.bytes[2] = (uint64_t)kChunkRows * kMaxGrid * sizeof(unsigned long long);
     cr.p[3] = c->t_counters.p; cr.bytes[3] = (all_counters ? (uint64_t)C_NUM : (uint64_t)kTableCounters) * sizeof(uint64_t);
     HIP_TRY(launch_clear(c->main_stream, cr));
@@ -356,7 +392,7 @@ static void table_swap_spare(vf_ctx *c) {
 static int table_make_spare(vf_ctx *c) {
     vf_ctx::Spare &sp = c->spare;
     int rc;
-    if ((rc = sp.slots.ensure(c->table_slots * 4)) || (rc = sp.counts.ensure(c->table_slots * kCountWords)) ||
+    if ((rc = sp.slots.ensure(c->table_slots * 4)) || (rc = sp.counts.ensure(c->table_slots)) ||
         (rc = sp.arena.ensure(c->arena_dwords)) || (rc = sp.counters.ensure(C_NUM)) ||
         (rc = sp.chunks.ensure((size_t)kChunkRows * kMaxGrid))) {
         sp.slots.release(); sp.counts.release(); sp.arena.release(); sp.counters.release(); sp.chunks.release();
@@ -421,7 +457,6 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     HIP_TRY(hipEventCreateWithFlags(&c->fin_event, hipEventDisableTiming));
     if (const char *e = getenv("VFIND_BLOCK_FILTER")) c->block_filter = atoi(e) != 0;
     if (const char *e = getenv("VFIND_TABLE_SPARE")) c->spare_on = atoi(e) != 0;
-    if (const char *e = getenv("VFIND_FOLD_LIMIT")) { const uint64_t v = strtoull(e, nullptr, 0); if (v >= 1 && v <= (1ull << 31)) c->fold_limit = v; }
     if (const char *e = getenv("VFIND_RES_LANES")) c->n_res = (uint32_t)std::min(std::max(atoi(e), 1), (int)vf_ctx::kMaxResLanes);
     for (uint32_t i = 0; i < c->n_res; ++i) {
         ResLane &L = c->res[i];
@@ -458,7 +493,7 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     // count table
     c->arena_dwords = (p->arena_bytes ? p->arena_bytes : (1ull << 30)) / 4;
     if ((rc = c->t_slots.ensure(c->table_slots * 4))) return rc;
-    if ((rc = c->t_counts.ensure(c->table_slots * kCountWords))) return rc;
+    if ((rc = c->t_counts.ensure(c->table_slots))) return rc;
     if ((rc = c->t_arena.ensure(c->arena_dwords))) return rc;
     if ((rc = c->t_counters.ensure(C_NUM))) return rc;
     if ((rc = c->t_chunks.ensure((size_t)kChunkRows * kMaxGrid))) return rc;
@@ -590,11 +625,11 @@ static int table_grow_locked(vf_ctx *c, bool use_unenqueued, uint64_t extra, uin
     while ((h[C_ENTRIES] + extra) * 2 > c->table_slots) {
         const uint64_t new_slots = c->table_slots * 4;
         if (new_slots > (1ull << 32)) return fail(VF_ECAPACITY, "device count table cannot grow beyond 2^32 slots");
-        DevBuf<uint4> n_slots; DevBuf<uint32_t> n_counts;
+        DevBuf<uint4> n_slots; DevBuf<unsigned long long> n_counts;
         if ((rc = n_slots.ensure(new_slots * 4))) return rc;
-        if ((rc = n_counts.ensure(new_slots * kCountWords))) { n_slots.release(); return rc; }
+        if ((rc = n_counts.ensure(new_slots))) { n_slots.release(); return rc; }
         HIP_TRY(hipMemsetAsync(n_slots.p, 0, new_slots * 64, c->main_stream));
-        HIP_TRY(hipMemsetAsync(n_counts.p, 0, new_slots * kCountWords * sizeof(uint32_t), c->main_stream));
+        HIP_TRY(hipMemsetAsync(n_counts.p, 0, new_slots * sizeof(unsigned long long), c->main_stream));
         HIP_TRY(hipMemsetAsync(c->t_counters.p + C_ENTRIES, 0, sizeof(uint64_t), c->main_stream));     // recounted by the re-insert
         HIP_TRY(hipMemsetAsync(c->t_counters.p + C_KEY_DWORDS, 0, sizeof(uint64_t), c->main_stream));
         Table to = c->tab;
@@ -619,28 +654,6 @@ static int table_grow_if_needed(vf_ctx *c, uint64_t entries_hint) {
     return table_grow_locked(c, false, 0);
 }
 
-// Called (without the table lock) before `add` more occurrences are handed to the device: a count word is 32 bits wide and
-// holds what its XCD counted for one key since the last fold, at most everything handed over since then.  The bound is
-// 2^31: what other threads have noted but not yet enqueued when a fold happens lands after it without being counted again
-// here - a few batches, far from the other 2^31.  A single batch beyond the bound (the resident path takes up to 2^32 - 16
-// reads) gets a fold before it and one before whatever follows it.  The fold excludes every submitter (table lock) and
-// waits for the device: it happens once per 2^31 reads.
-static int counts_note(vf_ctx *c, uint64_t add) {
-    std::lock_guard<std::mutex> g(c->fold_mu);
-    if (c->since_fold + add <= c->fold_limit) { c->since_fold += add; return VF_OK; }
-    if (c->since_fold != 0) {
-        std::unique_lock<std::shared_mutex> lk(c->table_mu);
-        int rc;
-        if ((rc = sync_all_streams(c))) return rc;
-        HIP_TRY(launch_fold(c->main_stream, c->tab));
-        HIP_TRY(hipStreamSynchronize(c->main_stream));
-        ++c->folds;
-        if (c->fold_limit != (1ull << 31)) fprintf(stderr, "vfind: count words folded into the base counts (%llu)\n", (unsigned long long)c->folds);   // test hook only
-    }
-    c->since_fold = add;
-    return VF_OK;
-}
-
 // streaming paths: every read of a batch may add a key, so a batch is only enqueued when the table
 // could take all of them (a conservative count, refreshed from the device whenever it runs out)
 struct CapacityTicket {
@@ -656,8 +669,6 @@ static inline uint64_t arena_need(const vf_ctx *c, uint32_t len) {
     return nd > kChunk / 4 ? nd + kChunk : nd + nd / 3 + 1;
 }
 static int reserve_capacity(vf_ctx *c, CapacityTicket &t, uint64_t n, uint64_t arena) {
-    int frc = counts_note(c, n);
-    if (frc) return frc;
     uint64_t up, upa;
     {
         std::lock_guard<std::mutex> g(c->cap_mu);
@@ -677,6 +688,7 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
     if (n == 0) return VF_OK;
     if (count) c->part_world = 0;
     if (n > 0xFFFFFFF0ull) return fail(VF_EINVAL, "batch too large (max 2^32-16 reads per submission)");
+    if (count) { const int lrc = ws.ensure_log(n, c->main_stream); if (lrc) return lrc; }
     BatchLists bl{};
     bl.listP = ws.listP.p; bl.listS = ws.listS.p; bl.listF = ws.listF.p;
     bl.cntP = ws.cnt.p; bl.cntS = ws.cnt.p + kMaxGrid; bl.cntF = ws.cnt.p + 2 * kMaxGrid;
@@ -715,8 +727,26 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
     if (count) HIP_TRY(hipStreamWaitEvent(st, c->clear_event, 0));
     // with a spare table nothing else orders the table kernels of two batch lanes: side by side they take 40 % longer each
     if (count && c->spare.valid && c->fin_recorded) HIP_TRY(hipStreamWaitEvent(st, c->fin_event, 0));
-    if (count) { Timed t(c, st, K_FIN); HIP_TRY(launch_finish(st, W, d_rows, d_lens, n, d_spans, c->skip_translation, tab)); }
+    // the previous log of this workspace has been applied (long ago, as a rule)
+    if (count && ws.log_pending) { HIP_TRY(hipStreamWaitEvent(st, ws.log_applied, 0)); ws.log_pending = false; }
+    if (count) { Timed t(c, st, K_FIN); HIP_TRY(launch_finish(st, W, d_rows, d_lens, n, d_spans, c->skip_translation, tab, ws.count_log())); }
     if (count && c->spare.valid) { HIP_TRY(hipEventRecord(c->fin_event, st)); c->fin_recorded = true; }
+    if (count) {
+        // The log is applied on the main stream: the batch's own stream goes on with its next batch, the other lane's
+        // k_finish (which reads no count) starts beside it, and whatever reads or drops counts - clear, export, merge,
+        // growth - is on the main stream behind it or synchronises it.
+        HIP_TRY(hipEventRecord(ws.log_written, st));
+        std::lock_guard<std::mutex> g(c->log_mu);                       // one log's kernels at a time on the main stream
+        HIP_TRY(hipStreamWaitEvent(c->main_stream, ws.log_written, 0));
+        {
+            Timed t(c, c->main_stream, K_LOG);
+            HIP_TRY(launch_count_log(c->main_stream, n, tab, ws.count_log()));
+            const CountLog l = ws.count_log();                          // part totals and scatter cursors: zero for the next batch
+            HIP_TRY(hipMemsetAsync(l.tot, 0, 4 * (size_t)kLogMaxParts * sizeof(uint32_t), c->main_stream));
+        }
+        HIP_TRY(hipEventRecord(ws.log_applied, c->main_stream));
+        ws.log_pending = true;
+    }
     // the entry count rides back with the batch: the host grows the table between batches when it fills
     if (count && h_entries) HIP_TRY(hipMemcpyAsync(h_entries, c->t_counters.p + C_ENTRIES, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     return VF_OK;
@@ -1048,7 +1078,6 @@ extern "C" int vf_process_device_packed(vf_ctx *c, const void *d_rows, uint32_t 
     if (L.in_flight && hipEventQuery(L.done) == hipSuccess) {           // lane idle: its entry count is current
         if ((rc = table_grow_if_needed(c, *L.h_entries.p))) return rc;
     }
-    if ((rc = counts_note(c, n))) return rc;
     std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
     if ((rc = L.ws.ensure(n))) return rc;
     short2 *spans = d_spans ? (short2 *)d_spans : L.ws.spans.p;
@@ -1080,6 +1109,7 @@ static int check_device_errors(vf_ctx *c, uint64_t *counters_out) {
     if (h[C_ERROR] & 1) return fail(VF_ECAPACITY, "device key arena full: raise arena_bytes");
     if (h[C_ERROR] & 2) return fail(VF_ECAPACITY, "device count table full: raise table_slots");
     if (h[C_ERROR] & 4) return fail(VF_ECAPACITY, "a variant region exceeds 65535 symbols");
+    if (h[C_ERROR] & 8) return fail(VF_EDEVICE, "count log: part totals and entries disagree (internal error)");
     return VF_OK;
 }
 
@@ -1122,10 +1152,8 @@ extern "C" int vf_table_clear(vf_ctx *c) {
         if (s->in_flight) HIP_TRY(hipStreamWaitEvent(c->main_stream, s->done, 0));
     for (auto &L : c->res)
         if (L.in_flight) HIP_TRY(hipStreamWaitEvent(c->main_stream, L.done, 0));
-    std::lock_guard<std::mutex> fold_lock(c->fold_mu);                  // (lock order: fold_mu, then the table lock - counts_note)
     std::unique_lock<std::shared_mutex> table_lock(c->table_mu);        // the table in use changes hands below
     { std::lock_guard<std::mutex> g(c->cap_mu); c->upper_entries = c->unenqueued; c->upper_arena = c->unenqueued_arena; }
-    c->since_fold = 0;                                                  // the table handed out next has empty count words
     for (auto &s : c->slots) if (s->h_entries.p) *s->h_entries.p = 0;  // (growth hints of the table being dropped)
     for (auto &L : c->res) if (L.h_entries.p) *L.h_entries.p = 0;
     c->part_world = 0;
@@ -1241,7 +1269,6 @@ extern "C" int vf_table_merge(vf_ctx *c, const void *d_blob, uint64_t nbytes) {
         std::lock_guard<std::mutex> g(c->cap_mu);
         c->upper_entries += hdr[0]; c->upper_arena += hdr[1];
     }
-    if ((rc = counts_note(c, hdr[0]))) return rc;      // (an entry of count 1 is one more in a 32-bit count word)
     std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
     c->part_world = 0;
     const uint8_t *b = (const uint8_t *)d_blob;
@@ -1510,6 +1537,7 @@ extern "C" int vf_stats_get(vf_ctx *c, vf_stats *o) {
     o->launches_scan = c->launches[K_SCAN]; o->launches_filter = c->launches[K_FILTER];
     o->launches_dp_window = c->launches[K_DPW]; o->launches_dp_rest = c->launches[K_DPREST];
     o->launches_finish = c->launches[K_FIN]; o->launches_generic = c->launches[K_GEN];
+    o->ms_count_log = c->ms[K_LOG]; o->launches_count_log = c->launches[K_LOG];
     return VF_OK;
 }
 extern "C" int vf_stats_reset(vf_ctx *c) {

@@ -1464,37 +1464,18 @@ __device__ __forceinline__ void slot_store_nowait(uint4 *p, u32x4 a, u32x4 b, u3
                  "global_store_dwordx4 %0, %4, off offset:48 sc1"
                  :: "v"(p), "v"(a), "v"(b), "v"(c), "v"(d) : "memory");
 }
-// The count words are 32 bits wide (half the count lines to clear, to keep in the caches and to write back; -3 % per
-// step of cfg 2): the host folds them into the 64-bit base counts (k_fold) before the reads counted since the last fold
-// could carry one over (vf_host.cpp, counts_note), and counts of any size (merge, growth) go to the base count directly.
-// Counts: one array per XCD (t.counts[xcd][slot]).  A count is bumped with an atomic that executes in
-// the issuing XCD's own L2 (no sc1): all CUs of an XCD share that L2, and no other XCD ever touches this
-// copy, so the add is coherent without going to the memory side - device-scope atomics do, and ~3 M of
-// them per 10 M reads cost more than everything else in k_finish together (measured: 0.45 ms of 0.55).
-// Readers (export, rehash) run in later kernels and sum the kXcds copies.
-__device__ __forceinline__ uint32_t xcc_id() {
-    // HW_REG_XCC_ID (id 20), bits [3:0]: s_getreg_b32 simm16 = (size-1)<<11 | offset<<6 | id
-    return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & (uint32_t)(kXcds - 1);
-}
-__device__ __forceinline__ void count_add(const Table &t, uint32_t xcc, uint32_t slot, uint32_t v) {
-    uint32_t *p = t.counts + (uint64_t)xcc * ((uint64_t)t.slot_mask + 1ull) + slot;
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ unsigned long long *count_base(const Table &t) {
-    return reinterpret_cast<unsigned long long *>(t.counts + (uint64_t)kXcds * ((uint64_t)t.slot_mask + 1ull));
-}
-// a count of any size, from any XCD (device scope: slow, and only merge / growth use it)
+// Counts: one 64-bit word per slot, apart from the slot lines, and k_finish never touches it.  An occurrence of a key
+// that is already in the table is written to the batch's count log as the key's slot index (CountLog, vf_device.h) and
+// applied after the kernel, range by range (k_log_apply).  Rounds 1-2 counted in place, with an atomic per occurrence
+// executed in the issuing XCD's L2 on one count array per XCD: every tail key then cost a count line fetched and written
+// back (384 MB of the 975 MB k_finish moved per 10 M reads) and - loads, stores and atomics of a wave retire in issue
+// order - every trip's slot lookup waited behind the count atomics of the trip before it.
+// A count of any size from anywhere (merge, growth, the byte-wise path): device scope, executed at the memory side.
 __device__ __forceinline__ void base_add(const Table &t, uint32_t slot, unsigned long long v) {
-    __hip_atomic_fetch_add(count_base(t) + slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint64_t count_get(const Table &t, uint64_t slot) {
-    uint64_t v = count_base(t)[slot];
-#pragma unroll
-    for (int x = 0; x < kXcds; ++x) v += t.counts[(uint64_t)x * ((uint64_t)t.slot_mask + 1ull) + slot];
-    return v;
+    __hip_atomic_fetch_add(t.counts + slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ uint64_t count_of(const Table &t, uint64_t slot, uint64_t w0) {      // the entry's count (see kW0One)
-    return count_get(t, slot) + ((w0 & kW0One) ? 1ull : 0ull);
+    return t.counts[slot] + ((w0 & kW0One) ? 1ull : 0ull);
 }
 
 // ---- workgroup-local state: arena chunks for LONG keys, insert counters --------------------------
@@ -1694,17 +1675,13 @@ __device__ __forceinline__ void table_add(const Table &t, BlockTable &bt, const 
     bool counted;
     const bool one = cnt == 1ull;
     const uint32_t slot = table_find_or_insert(t, bt, key, kind, len, active, have_off, one, counted);
-    if (slot != kNoSlot && !counted) {
-        if (one) count_add(t, xcc_id(), slot, 1u);
-        else base_add(t, slot, (unsigned long long)cnt);
-    }
+    if (slot != kNoSlot && !counted) base_add(t, slot, (unsigned long long)cnt);
 }
 
 // Workgroup-level count aggregation: a small LDS table keyed by slot index collects the +1s of a
-// whole workgroup (all its grid-stride iterations) and is flushed once at kernel end, so the Zipf
-// head of the variant distribution costs one global atomic per workgroup instead of one per read
-// (same-address global atomics serialise at ~10 ns each).  Slots that lose the LDS entry to another
-// slot fall through to a direct global atomic.
+// whole workgroup (all its grid-stride iterations); what it holds at kernel end goes to the count log as
+// (slot, count) pairs, so the Zipf head of the variant distribution costs one log entry per workgroup
+// instead of one per read.  A slot that loses the LDS entry to another slot is logged occurrence by occurrence.
 #ifndef VF_AGG_SIZE
 #define VF_AGG_SIZE 1024
 #endif
@@ -1716,17 +1693,43 @@ struct Agg {
 __device__ __forceinline__ void agg_init(Agg &a) {
     for (int i = threadIdx.x; i < kAggSize; i += kBlock) { a.slot[i] = kNoSlot; a.cnt[i] = 0; }
 }
-__device__ __forceinline__ void agg_add(Agg &a, const Table &t, uint32_t xcc, uint32_t slot) {
-    if (slot == kNoSlot) return;
+// true = counted here
+__device__ __forceinline__ bool agg_try(Agg &a, uint32_t slot) {
     const uint32_t i = ((slot * 0x9E3779B1u) >> 16) & (uint32_t)(kAggSize - 1);
     uint32_t cur = *(volatile uint32_t *)&a.slot[i];
     if (cur == kNoSlot) { cur = atomicCAS(&a.slot[i], kNoSlot, slot); if (cur == kNoSlot) cur = slot; }
-    if (cur == slot) atomicAdd(&a.cnt[i], 1u);
-    else count_add(t, xcc, slot, 1u);
+    if (cur != slot) return false;
+    atomicAdd(&a.cnt[i], 1u);
+    return true;
 }
-__device__ __forceinline__ void agg_flush(Agg &a, const Table &t, uint32_t xcc) {
+
+// ---- the count log as k_finish writes it (CountLog, vf_device.h) ---------------------------------
+// Per wave: a segment of slot indices, appended in place with one store per trip - the lanes that log write consecutive
+// dwords, the line fills up in L2 over the next trips and leaves it once.  Per workgroup: the (slot, count) pairs of the
+// aggregator and the key cache at kernel end, and the number of entries per slot part in LDS (s_tot), added to the
+// batch's totals when the workgroup is done: k_log_scatter turns the totals into part starts.
+struct WaveLog {
+    uint32_t *seg;                           // this wave's segment of log.one
+    uint32_t n;                              // entries written (wave-uniform)
+};
+__device__ __forceinline__ void log_one(WaveLog &wl, const CountLog &log, uint32_t *s_tot, uint32_t slot, bool want) {
+    const uint64_t m = __ballot(want);
+    if (!m) return;
+    if (want) {
+        const uint32_t at = wl.n + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+        if (at < log.cap_one) wl.seg[at] = slot;           // (cap_one = the reads a wave can see: never exceeded)
+        if (log.parts) atomicAdd(&s_tot[slot >> log.shift], 1u);
+    }
+    wl.n += (uint32_t)__popcll(m);
+}
+__device__ __forceinline__ void log_many(const CountLog &log, uint32_t *s_tot, uint32_t *s_nmany, uint32_t slot, uint32_t cnt) {
+    const uint32_t at = atomicAdd(s_nmany, 1u);
+    if (at < kLogMany) log.many[(uint64_t)blockIdx.x * kLogMany + at] = make_uint2(slot, cnt);
+    if (log.parts) atomicAdd(&s_tot[kLogMaxParts + (slot >> log.shift)], 1u);
+}
+__device__ __forceinline__ void agg_flush(Agg &a, const CountLog &log, uint32_t *s_tot, uint32_t *s_nmany) {
     for (int i = threadIdx.x; i < kAggSize; i += kBlock)
-        if (a.slot[i] != kNoSlot && a.cnt[i]) count_add(t, xcc, a.slot[i], a.cnt[i]);
+        if (a.slot[i] != kNoSlot && a.cnt[i]) log_many(log, s_tot, s_nmany, a.slot[i], a.cnt[i]);
 }
 
 // Workgroup-level key cache: the keys the workgroup has already found in the table, whole, in LDS.  A read whose key sits
@@ -1743,7 +1746,10 @@ __device__ __forceinline__ void agg_flush(Agg &a, const Table &t, uint32_t xcc) 
 constexpr int kKeyCacheSize = VF_KEYCACHE_SIZE;        // power of two
 struct KeyCache { u32x4 q[kKeyCacheSize][4]; };
 __device__ __forceinline__ void keycache_init(KeyCache &kc) {
-    for (int i = threadIdx.x; i < kKeyCacheSize; i += kBlock) { kc.q[i][0] = u32x4{0u, 0u, 0u, 0u}; kc.q[i][1] = u32x4{0u, 0u, 0u, 0u}; }
+    for (int i = threadIdx.x; i < kKeyCacheSize; i += kBlock) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kc.q[i][q] = u32x4{0u, 0u, 0u, 0u};
+    }
 }
 __device__ __forceinline__ uint32_t keycache_index(uint32_t h1) { return ((h1 * 0x9E3779B1u) >> 16) & (uint32_t)(kKeyCacheSize - 1); }
 // true = the key is cached and has been counted there
@@ -1752,7 +1758,10 @@ __device__ __forceinline__ bool keycache_hit(KeyCache &kc, uint32_t h1, uint32_t
     const uint32_t i = keycache_index(h1);
     const u32x4 t0 = *(volatile u32x4 *)&kc.q[i][0];
     if (t0.x != 2u || t0.y != h1 || t0.z != h2 || t0.w != meta) return false;
-    const u32x4 k0 = kc.q[i][2], k1 = kc.q[i][3];
+    // volatile like the state word: the compiler keeps the three LDS reads in program order and a wave's LDS operations
+    // execute in order, so the key words are read after the state said "ready" (a fence here would also wait for the
+    // row prefetch in flight)
+    const u32x4 k0 = *(volatile u32x4 *)&kc.q[i][2], k1 = *(volatile u32x4 *)&kc.q[i][3];
     const uint32_t diff = (k0.x ^ kin[0]) | (k0.y ^ kin[1]) | (k0.z ^ kin[2]) | (k0.w ^ kin[3]) |
                           (k1.x ^ kin[4]) | (k1.y ^ kin[5]) | (k1.z ^ kin[6]) | (k1.w ^ kin[7]);
     if (diff != 0u) return false;
@@ -1773,10 +1782,10 @@ __device__ __forceinline__ bool keycache_fill(KeyCache &kc, uint32_t h1, uint32_
     *(volatile uint32_t *)st = 2u;
     return true;
 }
-__device__ __forceinline__ void keycache_flush(KeyCache &kc, const Table &t, uint32_t xcc) {
+__device__ __forceinline__ void keycache_flush(KeyCache &kc, const CountLog &log, uint32_t *s_tot, uint32_t *s_nmany) {
     for (int i = threadIdx.x; i < kKeyCacheSize; i += kBlock) {
         const u32x4 t0 = kc.q[i][0], t1 = kc.q[i][1];
-        if (t0.x == 2u && t1.y) count_add(t, xcc, t1.x, t1.y);
+        if (t0.x == 2u && t1.y) log_many(log, s_tot, s_nmany, t1.x, t1.y);
     }
 }
 
@@ -1930,31 +1939,46 @@ __device__ __forceinline__ void slot_load2(const uint4 *p, const uint4 *q, uint4
 // lookup are queued per wave in LDS and handled 64 at a time by table_find_or_insert, so the insert
 // protocol's extra round trips are paid by full waves instead of by every wave that holds one new key.
 constexpr int kSlowCap = 192;
+#ifndef VF_FAST_INSERT_FROM
+#define VF_FAST_INSERT_FROM 2
+#endif
+constexpr uint64_t kFastInsertFromTrip = VF_FAST_INSERT_FROM;   // first trip of a launch on which the one-shot lookup may insert
 #ifndef VF_KEYCACHE
 #define VF_KEYCACHE 1
 #endif
 // (register caps through amdgpu_waves_per_eu were tried: 96 registers -> 32 bytes of scratch, two of its reloads on the path of
 // every trip: k_finish +15 %, k_scan beside it -8 % with its third wave per SIMD, the step +2 %; 80 registers -> +20 %)
 #define VF_FINISH_ATTR __launch_bounds__(kBlock)
+#ifdef VF_FINISH_ABLATION
+// diagnosis build: per wave of k_finish, 10 ns ticks (s_memrealtime): [0] start, [1..8] after trip 0,1,2,4,8,16,32,last,
+// [9] end, [10] insert-queue batches run, [11] ticks spent in them
+__device__ uint64_t g_fin_trace[kMaxGrid * (kBlock / WAVE)][12];
+#define VF_FIN_STAMP(i) do { if (lane_id() == 0) g_fin_trace[blockIdx.x * (kBlock / WAVE) + threadIdx.x / WAVE][i] = wall_clock64(); } while (0)
+#else
+#define VF_FIN_STAMP(i) do { } while (0)
+#endif
 template <int W, int U, bool DNA, int DBG = 0>
 __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens,
-                                                   uint64_t n_reads, const short2 *__restrict__ spans, Table t) {
+                                                   uint64_t n_reads, const short2 *__restrict__ spans, Table t, CountLog log) {
     using FK = FinishKey<W, DNA>;
     constexpr int ND = FK::ND;
     __shared__ uint8_t lut[64];
     __shared__ Agg agg;
     __shared__ KeyCache kc;
     __shared__ BlockTable bt;
-    __shared__ uint32_t s_stat[3];
+    __shared__ uint32_t s_stat[4];                // accepted, counted, slow, (slot, count) pairs logged
     __shared__ uint32_t s_slow[kBlock / WAVE][kSlowCap];
+    extern __shared__ uint32_t s_tot[];           // [2][kLogMaxParts] log entries per slot part (log.parts != 0 only)
     if (threadIdx.x < 64) lut[threadIdx.x] = c_codon_le[threadIdx.x];
-    if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
+    if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
+    if (log.parts) for (uint32_t i = threadIdx.x; i < 2 * kLogMaxParts; i += kBlock) s_tot[i] = 0;
     agg_init(agg);
     keycache_init(kc);
     block_table_begin(bt, t);
     __syncthreads();
     const uint32_t lane = lane_id();
-    const uint32_t xcc = xcc_id();
+    const uint32_t gwave = blockIdx.x * (kBlock / WAVE) + threadIdx.x / WAVE;
+    WaveLog wl{log.one + (uint64_t)gwave * log.cap_one, 0u};
     uint32_t *slow = s_slow[threadIdx.x / WAVE];
     uint32_t nslow = 0;                           // wave-uniform
     const uint64_t gstride = (uint64_t)gridDim.x * kBlock;
@@ -1980,6 +2004,10 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
 #pragma unroll
     for (int u = 0; u < U; ++u) prefetch(u, tid + (uint64_t)u * gstride);
 
+    VF_FIN_STAMP(0);
+#ifdef VF_FINISH_ABLATION
+    uint64_t dbg_batches = 0, dbg_ticks = 0;
+#endif
     for (uint64_t trip = 0; trip <= n_trips; ++trip) {
         const bool last = trip == n_trips;        // the extra trip only drains the slow list
         if (!last) {
@@ -2013,9 +2041,10 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
                     n_act += (uint32_t)__popcll(__ballot(act[u]));
                 }
                 if (lane == 0) { atomicAdd(&s_stat[0], n_ok); atomicAdd(&s_stat[1], n_act); }
-                bool found[U], cached[U];
+                bool found[U], cached[U], inserted[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
+                    inserted[u] = false;
                     cached[u] = VF_KEYCACHE && keycache_hit(kc, fp[u].h1, fp[u].h2, fp[u].meta, fp[u].kin, fp[u].can && fp[u].nd <= 8u);
                     fp[u].can = fp[u].can && !cached[u];
 #ifdef VF_FINISH_ABLATION
@@ -2034,17 +2063,43 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         uint4 a, b, c, d;
-                        slot_load_key(t.slots + (uint64_t)fp[u].slot * 4, fp[u].nd, fp[u].can, a, b, c, d);
+                        uint4 *sp = t.slots + (uint64_t)fp[u].slot * 4;
+                        slot_load_key(sp, fp[u].nd, fp[u].can, a, b, c, d);
                         found[u] = fast_check(fp[u], a, b, c, d);
+                        // A new key whose home slot is empty is inserted right here (letter keys: they validate themselves, so
+                        // the claim is READY at once and the line is stored without a wait - table_find_or_insert's selfval
+                        // case): one CAS round trip for the wave instead of a place in the insert queue, a second load of the
+                        // row, a second translation and the claim loop's trips (0.65 M of the 0.8 M new keys of a cold cfg-2
+                        // step).  Not on the first trips of a launch: there every lane that holds a hot key still finds the
+                        // slot empty, and thousands of CAS on one address serialise (the queue spreads them out).
+                        if constexpr (!DNA) {
+                            const bool empty = fp[u].can && (a.x | a.y) == 0u && trip >= kFastInsertFromTrip;
+                            if (__any(empty)) {
+                                const uint64_t w0claim = fp[u].w0want | kW0One;
+                                unsigned long long old = 1ull;
+                                if (empty) old = atomicCAS(reinterpret_cast<unsigned long long *>(sp), 0ull, (unsigned long long)w0claim);
+                                const bool won = empty && old == 0ull;
+                                if (won) {
+                                    const uint32_t (&kin)[kInlineDwords] = fp[u].kin;
+                                    slot_store_nowait(sp, u32x4{(uint32_t)w0claim, (uint32_t)(w0claim >> 32), kin[0], kin[1]}, u32x4{kin[2], kin[3], kin[4], kin[5]},
+                                                      u32x4{kin[6], kin[7], kin[8], kin[9]}, u32x4{kin[10], kin[11], kin[12], kin[13]});
+                                    atomicAdd(&bt.new_entries, 1u);
+                                    atomicAdd(&bt.new_key_dwords, fp[u].nd);
+                                }
+                                inserted[u] = won;
+                            }
+                        }
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
+                    bool to_log = false;
                     if (found[u] && DBG != 3 && DBG != 4) {
                         const bool entered = VF_KEYCACHE && fp[u].nd <= 8u && keycache_fill(kc, fp[u].h1, fp[u].h2, fp[u].meta, fp[u].kin, fp[u].slot);
-                        if (!entered) agg_add(agg, t, xcc, fp[u].slot);
+                        to_log = !entered && !agg_try(agg, fp[u].slot);
                     }
-                    const bool miss = act[u] && !found[u] && !cached[u];
+                    log_one(wl, log, s_tot, fp[u].slot, to_log);
+                    const bool miss = act[u] && !found[u] && !cached[u] && !inserted[u];
                     const uint64_t m = __ballot(miss);
                     if (miss) slow[nslow + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r[u];
                     nslow += (uint32_t)__popcll(m);
@@ -2054,7 +2109,19 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
             }
         }
         __builtin_amdgcn_wave_barrier();
+#ifdef VF_FINISH_ABLATION
+        if (!last) {
+            if (trip == 0) VF_FIN_STAMP(1); else if (trip == 1) VF_FIN_STAMP(2); else if (trip == 2) VF_FIN_STAMP(3); else if (trip == 4) VF_FIN_STAMP(4);
+            else if (trip == 8) VF_FIN_STAMP(5); else if (trip == 16) VF_FIN_STAMP(6); else if (trip == 32) VF_FIN_STAMP(7);
+            if (trip + 1 == n_trips) VF_FIN_STAMP(8);
+        }
+        const uint64_t dbg_t0 = wall_clock64();
+        const uint32_t dbg_n0 = nslow;
+#endif
         while (nslow >= (last ? 1u : (uint32_t)WAVE)) {
+#ifdef VF_FINISH_ABLATION
+            ++dbg_batches;
+#endif
             const uint32_t cnt = nslow < (uint32_t)WAVE ? nslow : (uint32_t)WAVE;
             const uint32_t base = nslow - cnt;
             const bool mine = lane < cnt;
@@ -2073,20 +2140,158 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
             finish_key<W, DNA>(xs, sp.x, sp.y, oks, lut, ks, ls, as);
             bool counted;
             const uint32_t sl = table_find_or_insert(t, bt, RegKey<ND>{ks}, FK::kKind, ls, as, kNoOff, true, counted);
-            if (!counted) agg_add(agg, t, xcc, sl);
+            log_one(wl, log, s_tot, sl, sl != kNoSlot && !counted && !agg_try(agg, sl));
             nslow = base;
             __builtin_amdgcn_wave_barrier();
         }
+#ifdef VF_FINISH_ABLATION
+        if (dbg_n0 != nslow) dbg_ticks += wall_clock64() - dbg_t0;
+#endif
     }
+#ifdef VF_FINISH_ABLATION
+    VF_FIN_STAMP(9);
+    if (lane == 0) { g_fin_trace[gwave][10] = dbg_batches; g_fin_trace[gwave][11] = dbg_ticks; }
+#endif
+    if (lane == 0) log.n_one[gwave] = wl.n < log.cap_one ? wl.n : log.cap_one;
     __syncthreads();
-    agg_flush(agg, t, xcc);
-    keycache_flush(kc, t, xcc);
+    agg_flush(agg, log, s_tot, &s_stat[3]);
+    keycache_flush(kc, log, s_tot, &s_stat[3]);
     block_table_end(bt, t);
+    __syncthreads();
+    if (log.parts)
+        for (uint32_t i = threadIdx.x; i < 2 * kLogMaxParts; i += kBlock) {
+            const uint32_t v = s_tot[i];
+            if (v) atomicAdd(&log.tot[i], v);
+        }
     if (threadIdx.x == 0) {
+        log.n_many[blockIdx.x] = s_stat[3] < kLogMany ? s_stat[3] : kLogMany;
         if (s_stat[0]) atomicAdd((unsigned long long *)&t.counters[C_ACCEPTED], (unsigned long long)s_stat[0]);
         if (s_stat[1]) atomicAdd((unsigned long long *)&t.counters[C_COUNTED], (unsigned long long)s_stat[1]);
         if (s_stat[2]) atomicAdd((unsigned long long *)&t.counters[C_SLOW], (unsigned long long)s_stat[2]);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the count log applied (CountLog, vf_device.h): the reduce of lib.rs:292-306 for a whole batch
+// ------------------------------------------------------------------------------------------------
+// exclusive prefix of v[0..n) over the workgroup (n <= kLogMaxParts <= kBlock), result in out[0..n], out[n] = total
+__device__ __forceinline__ void part_starts(const uint32_t *__restrict__ tot, uint32_t n, uint32_t *out) {
+    static_assert(kLogMaxParts <= (uint32_t)kBlock, "one thread per part");
+    __shared__ uint32_t s_wave[kBlock / WAVE];
+    const uint32_t i = threadIdx.x;
+    const uint32_t v = i < n ? tot[i] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if ((int)lane_id() >= d) incl += up;
+    }
+    if (lane_id() == WAVE - 1) s_wave[i / WAVE] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < i / WAVE; ++w) base += s_wave[w];
+    if (i < n) out[i] = base + incl - v;
+    if (i == kBlock - 1) out[n] = base + incl;
+    __syncthreads();
+}
+
+// One workgroup per workgroup of k_finish: its four wave segments and its pairs, grouped by slot part.  A run per part is
+// reserved in the part's stretch of the output with one atomic (the totals say where the stretch starts), the entries
+// take their places inside the run through LDS counters; the 4-byte stores of a run fill its lines in L2.
+__global__ __launch_bounds__(kBlock) void k_log_scatter(CountLog log, uint64_t *__restrict__ counters) {
+    __shared__ uint32_t s_start[2][kLogMaxParts + 1];     // part starts (one, many)
+    __shared__ uint32_t s_n[2][kLogMaxParts];             // this workgroup's entries per part, then its cursor
+    __shared__ uint32_t s_base[2][kLogMaxParts];
+    const uint32_t P = log.parts;
+    part_starts(log.tot, P, s_start[0]);
+    part_starts(log.tot + kLogMaxParts, P, s_start[1]);
+    for (uint32_t i = threadIdx.x; i < 2 * kLogMaxParts; i += kBlock) (&s_n[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t b = blockIdx.x;
+    const uint32_t n_many = log.n_many[b];
+    const uint2 *many = log.many + (uint64_t)b * kLogMany;
+    // count
+    for (uint32_t w = 0; w < kBlock / WAVE; ++w) {
+        const uint32_t gw = b * (kBlock / WAVE) + w, n = log.n_one[gw];
+        const uint32_t *seg = log.one + (uint64_t)gw * log.cap_one;
+        for (uint32_t i = threadIdx.x; i < n; i += kBlock) atomicAdd(&s_n[0][seg[i] >> log.shift], 1u);
+    }
+    for (uint32_t i = threadIdx.x; i < n_many; i += kBlock) atomicAdd(&s_n[1][many[i].x >> log.shift], 1u);
+    __syncthreads();
+    // reserve
+    for (uint32_t i = threadIdx.x; i < 2 * P; i += kBlock) {
+        const uint32_t k = i / P, p = i % P, n = s_n[k][p];
+        s_base[k][p] = s_start[k][p] + (n ? atomicAdd(&log.cur[k * kLogMaxParts + p], n) : 0u);
+        s_n[k][p] = 0;
+    }
+    __syncthreads();
+    // place
+    bool bad = false;
+    for (uint32_t w = 0; w < kBlock / WAVE; ++w) {
+        const uint32_t gw = b * (kBlock / WAVE) + w, n = log.n_one[gw];
+        const uint32_t *seg = log.one + (uint64_t)gw * log.cap_one;
+        for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+            const uint32_t slot = seg[i], p = slot >> log.shift;
+            const uint64_t at = (uint64_t)s_base[0][p] + atomicAdd(&s_n[0][p], 1u);
+            if (at < log.cap_total) log.one_by_part[at] = slot; else bad = true;
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n_many; i += kBlock) {
+        const uint2 e = many[i];
+        const uint32_t p = e.x >> log.shift;
+        const uint64_t at = (uint64_t)s_base[1][p] + atomicAdd(&s_n[1][p], 1u);
+        if (at < (uint64_t)log.grid * kLogMany) log.many_by_part[at] = e; else bad = true;
+    }
+    if (bad) atomicOr((unsigned long long *)&counters[C_ERROR], 8ull);      // totals and log disagree: never seen, never silent
+}
+
+// One workgroup per range of kLogRange slots: the entries of the range's part are counted in LDS (the part's other
+// ranges are skipped over: a part is read by every workgroup of its ranges, from L2), then the counts go to the table's
+// 64-bit words, consecutive addresses, once per slot and batch.
+__global__ __launch_bounds__(kBlock) void k_log_apply(Table t, CountLog log) {
+    __shared__ uint32_t s_h[kLogRange];
+    __shared__ uint32_t s_start[2][kLogMaxParts + 1];
+    const uint32_t P = log.parts;
+    part_starts(log.tot, P, s_start[0]);
+    part_starts(log.tot + kLogMaxParts, P, s_start[1]);
+    const uint64_t nslots = (uint64_t)t.slot_mask + 1;
+    const uint32_t R = nslots < kLogRange ? (uint32_t)nslots : kLogRange;
+    const uint64_t n_ranges = nslots / R;
+    for (uint64_t r = blockIdx.x; r < n_ranges; r += gridDim.x) {
+        const uint32_t lo = (uint32_t)(r * R), p = lo >> log.shift;
+        const uint32_t a1 = s_start[0][p], b1 = s_start[0][p + 1], a2 = s_start[1][p], b2 = s_start[1][p + 1];
+        if (a1 == b1 && a2 == b2) continue;                           // (workgroup-uniform)
+        for (uint32_t i = threadIdx.x; i < R; i += kBlock) s_h[i] = 0;
+        __syncthreads();
+        for (uint32_t i = a1 + threadIdx.x; i < b1; i += kBlock) {
+            const uint32_t d = log.one_by_part[i] - lo;
+            if (d < R) atomicAdd(&s_h[d], 1u);
+        }
+        for (uint32_t i = a2 + threadIdx.x; i < b2; i += kBlock) {
+            const uint2 e = log.many_by_part[i];
+            const uint32_t d = e.x - lo;
+            if (d < R) atomicAdd(&s_h[d], e.y);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < R; i += kBlock) {
+            const uint32_t h = s_h[i];
+            if (h) base_add(t, lo + i, (unsigned long long)h);
+        }
+        __syncthreads();
+    }
+}
+
+// parts == 0 (a table of so many ranges that a batch touches few of them): entry by entry
+__global__ __launch_bounds__(kBlock) void k_log_direct(Table t, CountLog log) {
+    const uint32_t b = blockIdx.x;
+    for (uint32_t w = 0; w < kBlock / WAVE; ++w) {
+        const uint32_t gw = b * (kBlock / WAVE) + w, n = log.n_one[gw];
+        const uint32_t *seg = log.one + (uint64_t)gw * log.cap_one;
+        for (uint32_t i = threadIdx.x; i < n; i += kBlock) base_add(t, seg[i], 1ull);
+    }
+    const uint32_t n_many = log.n_many[b];
+    const uint2 *many = log.many + (uint64_t)b * kLogMany;
+    for (uint32_t i = threadIdx.x; i < n_many; i += kBlock) base_add(t, many[i].x, (unsigned long long)many[i].y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2663,34 +2868,79 @@ hipError_t launch_bmfilter(hipStream_t s, int W, const uint32_t *rows, const uin
 }
 
 
+// workgroups per CU of k_finish.  Three measured best next to a second batch lane (10.5 vs 10.3 at two and 10.1 G reads/s
+// at four, interleaved runs): the kernel is bound by the memory side (slot lines, CAS), more resident waves add
+// contention there and take registers from the DP waves of the other lane
+static int finish_per_cu() {
+    static const int per_cu = [] { const char *v = getenv("VFIND_FINISH_BLOCKS_PER_CU"); const int x = v ? atoi(v) : 3; return x >= 1 && x <= 8 ? x : 3; }();
+    return per_cu;
+}
+static bool finish_u2() {
+    static const bool u2 = [] { const char *v = getenv("VFIND_FINISH_U"); return v && atoi(v) == 2; }();
+    return u2;
+}
+// what a k_finish launch over n reads needs of the count log: workgroups, entries per wave segment, entries in all
+uint64_t count_log_entries(uint64_t n, uint32_t *grid, uint32_t *cap_one) {
+    const uint32_t g = (uint32_t)grid_for(n, finish_per_cu());
+    const uint64_t gstride = (uint64_t)g * kBlock;
+    const uint64_t per_wave = (n + gstride - 1) / gstride * WAVE;      // a wave sees this many reads (U reads a lane and trip: same total)
+    const uint64_t cap = (per_wave + 2 * WAVE + 15) / 16 * 16;          // (U = 2 rounds the trips up to pairs)
+    *grid = g;
+    *cap_one = (uint32_t)cap;
+    return cap * g * (kBlock / WAVE);
+}
+// slot parts of the count log for a table of `slots` slots and a batch of n reads: parts = 0 -> k_log_direct
+static void count_log_parts(uint64_t slots, uint64_t n, uint32_t *parts, uint32_t *shift) {
+    static const int force = [] { const char *v = getenv("VFIND_COUNT_LOG"); return v ? atoi(v) : 0; }();   // 1 direct, 2 by parts (A/B runs, tests)
+    // by parts pays when the batch touches most ranges: a workgroup per range zeroes and walks 32 KiB of LDS whether
+    // the range got entries or not, and every part is read by all of its ranges
+    bool by_parts = slots <= (1ull << 26) && n >= slots / 64;
+    if (force == 1) by_parts = false;
+    if (force == 2 && slots <= (1ull << 31)) by_parts = true;
+    if (!by_parts) { *parts = 0; *shift = 0; return; }
+    uint32_t sh = 0;
+    while ((slots >> sh) > kLogMaxParts) ++sh;                          // parts = slots >> shift <= kLogMaxParts, a power of two
+    const uint32_t range_sh = 13;                                       // kLogRange = 2^13: a range never straddles two parts
+    static_assert(kLogRange == 1u << 13, "range shift");
+    if (sh < range_sh && slots > kLogRange) sh = range_sh;
+    if (slots <= kLogRange) sh = 31;                                    // one range, one part
+    *shift = sh;
+    *parts = (uint32_t)((slots - 1) >> sh) + 1u;
+}
+
 hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n, const short2 *spans,
-                         bool skip_translation, Table t) {
+                         bool skip_translation, Table t, CountLog log) {
     if (n == 0) return hipSuccess;
     if (n >> 32) return hipErrorInvalidValue;         // read indices are 32-bit in the work lists
     hipError_t e = ensure_lut();
     if (e != hipSuccess) return e;
-    // three workgroups per CU measured best next to a second batch lane (10.5 vs 10.3 at two and 10.1 G reads/s at four,
-    // interleaved runs): the kernel is bound by the memory side (slot lines, count lines, CAS), more resident waves add
-    // contention there and take registers from the DP waves of the other lane
-    static const int per_cu = [] { const char *v = getenv("VFIND_FINISH_BLOCKS_PER_CU"); const int x = v ? atoi(v) : 3; return x >= 1 && x <= 8 ? x : 3; }();
     // one read per lane and trip measured best once the kernel runs two workgroups per CU (7.44 vs 7.23 G reads/s over
     // four interleaved runs each): the 105-VGPR variant leaves more of the register file to the other batch lane
-    static const bool u2 = [] { const char *v = getenv("VFIND_FINISH_U"); return v && atoi(v) == 2; }();
-    const int g = grid_for(n, per_cu);
+    const bool u2 = finish_u2();
+    uint32_t g_log, cap_one;
+    const uint64_t need = count_log_entries(n, &g_log, &cap_one);
+    const int g = (int)g_log;
+    if (log.cap_total < need || !log.one || !log.n_one || !log.many || !log.n_many) return hipErrorInvalidValue;
+    log.cap_one = cap_one;
+    log.grid = g_log;
+    count_log_parts((uint64_t)t.slot_mask + 1, n, &log.parts, &log.shift);
+    // (tot[2][..] and cur[2][..] are zero: the caller resets them when it starts the batch, off the table kernels' path)
+    if (log.parts && (!log.tot || !log.cur || !log.one_by_part || !log.many_by_part)) return hipErrorInvalidValue;
+    const size_t dyn = log.parts ? 2 * kLogMaxParts * sizeof(uint32_t) : 0;
 #define VF_FINISH(WW, UU)                                                                                              \
     do {                                                                                                               \
-        if (skip_translation) hipLaunchKernelGGL((k_finish<WW, UU, true>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t); \
-        else hipLaunchKernelGGL((k_finish<WW, UU, false>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t);               \
+        if (skip_translation) hipLaunchKernelGGL((k_finish<WW, UU, true>), dim3(g), dim3(kBlock), dyn, s, rows, lens, n, spans, t, log); \
+        else hipLaunchKernelGGL((k_finish<WW, UU, false>), dim3(g), dim3(kBlock), dyn, s, rows, lens, n, spans, t, log);               \
     } while (0)
     switch (W) {
     case 10: {
 #ifdef VF_FINISH_ABLATION      // diagnosis build only (make ablation): these variants give wrong counts by construction
         static const int dbg = [] { const char *v = getenv("VFIND_FINISH_DBG"); return v ? atoi(v) : 0; }();
-        if (dbg == 9) break;                      // no table kernel at all: what the chains of two lanes do on their own
-        if (dbg == 1) { hipLaunchKernelGGL((k_finish<10, 2, false, 1>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t); break; }
-        if (dbg == 2) { hipLaunchKernelGGL((k_finish<10, 2, false, 2>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t); break; }
-        if (dbg == 3) { hipLaunchKernelGGL((k_finish<10, 2, false, 3>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t); break; }
-        if (dbg == 4) { hipLaunchKernelGGL((k_finish<10, 2, false, 4>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, spans, t); break; }
+        if (dbg == 9) return hipSuccess;          // no table kernel at all: what the chains of two lanes do on their own
+        if (dbg == 1) { hipLaunchKernelGGL((k_finish<10, 2, false, 1>), dim3(g), dim3(kBlock), dyn, s, rows, lens, n, spans, t, log); break; }
+        if (dbg == 2) { hipLaunchKernelGGL((k_finish<10, 2, false, 2>), dim3(g), dim3(kBlock), dyn, s, rows, lens, n, spans, t, log); break; }
+        if (dbg == 3) { hipLaunchKernelGGL((k_finish<10, 2, false, 3>), dim3(g), dim3(kBlock), dyn, s, rows, lens, n, spans, t, log); break; }
+        if (dbg == 4) { hipLaunchKernelGGL((k_finish<10, 2, false, 4>), dim3(g), dim3(kBlock), dyn, s, rows, lens, n, spans, t, log); break; }
 #endif
         if (u2) VF_FINISH(10, 2); else VF_FINISH(10, 1);
         break;
@@ -2700,6 +2950,30 @@ hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint1
     default: return hipErrorInvalidValue;
     }
 #undef VF_FINISH
+    return hipGetLastError();
+}
+
+// the count log of the k_finish launch over the same n reads, applied to the table's counts (nothing in k_finish reads a
+// count, so the next batch's k_finish may run beside this)
+hipError_t launch_count_log(hipStream_t s, uint64_t n, Table t, CountLog log) {
+    if (n == 0) return hipSuccess;
+    uint32_t g_log, cap_one;
+    (void)count_log_entries(n, &g_log, &cap_one);
+    const int g = (int)g_log;
+    log.cap_one = cap_one;
+    log.grid = g_log;
+    count_log_parts((uint64_t)t.slot_mask + 1, n, &log.parts, &log.shift);
+#ifdef VF_FINISH_ABLATION
+    { static const int dbg = [] { const char *v = getenv("VFIND_FINISH_DBG"); return v ? atoi(v) : 0; }(); if (dbg == 9) return hipSuccess; }
+#endif
+    if (log.parts) {
+        hipLaunchKernelGGL(k_log_scatter, dim3(g), dim3(kBlock), 0, s, log, t.counters);
+        const uint64_t nslots = (uint64_t)t.slot_mask + 1;
+        const uint64_t ranges = nslots <= kLogRange ? 1 : nslots / kLogRange;
+        hipLaunchKernelGGL(k_log_apply, dim3((unsigned)std::min<uint64_t>(ranges, kMaxGrid)), dim3(kBlock), 0, s, t, log);
+    } else {
+        hipLaunchKernelGGL(k_log_direct, dim3(g), dim3(kBlock), 0, s, t, log);
+    }
     return hipGetLastError();
 }
 
@@ -2766,30 +3040,13 @@ __global__ __launch_bounds__(kBlock) void k_clear(ClearRegions cr) {
 }
 
 #ifdef VF_FINISH_ABLATION
+extern "C" int vf_debug_fin_trace(uint64_t *out) {         // diagnosis build: kMaxGrid x 4 waves x 12 words
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_trace), sizeof(uint64_t) * kMaxGrid * (kBlock / WAVE) * 12) == hipSuccess ? 0 : 4;
+}
 extern "C" int vf_debug_dp_trace(uint64_t *out) {          // diagnosis build: 2 x kMaxGrid x 4 words
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dp_trace), sizeof(uint64_t) * 2 * kMaxGrid * 4) == hipSuccess ? 0 : 4;
 }
 #endif
-
-// the 32-bit count words of every slot into its base count (see count_add); nothing else may touch the table meanwhile
-__global__ __launch_bounds__(kBlock) void k_fold(Table t) {
-    const uint64_t nslots = (uint64_t)t.slot_mask + 1;
-    unsigned long long *base = count_base(t);
-    for (uint64_t s = (uint64_t)blockIdx.x * kBlock + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * kBlock) {
-        uint64_t v = 0;
-#pragma unroll
-        for (int x = 0; x < kXcds; ++x) {
-            uint32_t *p = t.counts + (uint64_t)x * nslots + s;
-            const uint32_t w = *p;
-            if (w) { v += w; *p = 0u; }
-        }
-        if (v) base[s] += v;
-    }
-}
-hipError_t launch_fold(hipStream_t s, Table t) {
-    hipLaunchKernelGGL(k_fold, dim3(grid_for((uint64_t)t.slot_mask + 1, 8)), dim3(kBlock), 0, s, t);
-    return hipGetLastError();
-}
 
 hipError_t launch_clear(hipStream_t s, const ClearRegions &cr) {
     for (int q = 0; q < 4; ++q)
