@@ -123,3 +123,32 @@ def test_rust_shim_declares_the_same_entry_points():
     body = rs[rs.index("pub struct VfStats"):rs.index('extern "C" {')]
     n_fields = len(re.findall(r"pub [a-z0-9_]+: (?:u64|f64)", body)) + 4 * len(re.findall(r"\[u64; 4\]", body))
     assert n_fields * 8 == C.sizeof(_lib.VfStats)
+
+
+def test_exception_barrier_returns_a_code(monkeypatch):
+    """include/vfind_hip.h: no exception crosses the ABI.  With the test hook that makes vf_finish throw, the entry point
+    comes back with an error code and a message (no GPU is needed to get that far) - the process is still here to assert it"""
+    from vfind_amd import _lib
+    L = _lib.lib()
+    out = C.c_void_p()
+    monkeypatch.setenv("VFIND_TEST_THROW", "finish")
+    assert L.vf_finish(None, C.byref(out)) == _lib.VF_ENOMEM
+    assert b"out of host memory" in L.vf_last_error()
+    monkeypatch.setenv("VFIND_TEST_THROW", "finish_length")
+    assert L.vf_finish(None, C.byref(out)) == _lib.VF_EDEVICE
+    assert b"internal error" in L.vf_last_error()
+    monkeypatch.delenv("VFIND_TEST_THROW")
+    assert L.vf_finish(None, C.byref(out)) == _lib.VF_EINVAL
+
+
+def test_every_entry_point_sits_behind_the_barrier():
+    """each `extern "C" int vf_*` of the library's sources is a one-line wrapper around vf_guard"""
+    n = 0
+    for f in ("vf_host.cpp", "vf_fastq.cpp", "vf_arrow.cpp"):
+        src = open(os.path.join(ROOT, "vfind_amd", "csrc", f)).read()
+        for m in re.finditer(r'^extern "C" int (vf_\w+)\(.*$', src, re.M):
+            if m.group(1) == "vf_abi_version":
+                continue
+            assert "vf_guard(" in m.group(0), m.group(0)
+            n += 1
+    assert n >= 25

@@ -594,6 +594,33 @@ def test_table_grows_between_batches():
         assert len(got) > 5000
 
 
+def test_exception_barrier_at_the_c_abi(monkeypatch):
+    """a C++ exception inside an entry point - std::bad_alloc, a length_error from a vector sized by a bad value, anything thrown
+    on a worker thread of the FASTQ reader - comes back as an error code and a message (round 2's r2o_edge.log: a garbage size
+    into resize() inside vf_finish ended the Python process); the context is still usable afterwards"""
+    import vfind_amd
+    reads = synth.make_reads(61, 3000, AD20, L=150, n_variants=100)
+    with _engine(AD20) as e:
+        e.submit(reads)
+        monkeypatch.setenv("VFIND_TEST_THROW", "finish")
+        with pytest.raises(MemoryError, match="out of host memory"):
+            e.finish_dict()
+        monkeypatch.setenv("VFIND_TEST_THROW", "finish_length")
+        with pytest.raises(vfind_amd.VfindError, match="internal error"):
+            e.finish_dict()
+        monkeypatch.delenv("VFIND_TEST_THROW")
+        assert e.finish_dict() == oracle.count(reads, AD20)
+    toy = os.path.join(os.path.dirname(__file__), "golden", "toy.fq.gz")
+    toy_ads = ("GGGCCCAGCCGGCCGGAT", "CCGGAGGCGGAGGTTCAG")
+    monkeypatch.setenv("VFIND_TEST_THROW", "fastq_worker")
+    with pytest.raises(vfind_amd.VfindError, match="worker thread"):
+        vfind_amd.find_variants(toy, toy_ads, show_progress=False)
+    monkeypatch.delenv("VFIND_TEST_THROW")
+    with vfind_amd.Engine(toy_ads) as e:
+        e.run_fastq(toy)
+        assert e.finish_dict() == {b"MAGICAL": 4}
+
+
 def test_capacity_error_is_loud():
     """streaming submits reserve room before they are enqueued (the table grows first), so a tiny table
     still gives the oracle's answer; a resident batch larger than the table cannot be saved and fails loudly,

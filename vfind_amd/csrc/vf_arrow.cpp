@@ -58,7 +58,9 @@ ArrowSchema *child_schema(const char *fmt, const char *name) {
 
 }  // namespace
 
-extern "C" int vf_result_export_arrow(vf_result *r, ArrowArray *out_array, ArrowSchema *out_schema) {
+static int vf_result_export_arrow_impl(vf_result *r, ArrowArray *out_array, ArrowSchema *out_schema);
+extern "C" int vf_result_export_arrow(vf_result *r, ArrowArray *out_array, ArrowSchema *out_schema) { return vf_guard([&] { return vf_result_export_arrow_impl(r, out_array, out_schema); }); }
+static int vf_result_export_arrow_impl(vf_result *r, ArrowArray *out_array, ArrowSchema *out_schema) {
     if (!r || !out_array || !out_schema) return vf_internal_fail(VF_EINVAL, "null argument");
     const int64_t rows = (int64_t)r->counts.size();
     if (r->offsets.size() != (size_t)rows + 1) return vf_internal_fail(VF_EINVAL, "result already exported");

@@ -121,7 +121,10 @@ struct Table {
 // in LDS and adds what it has to the 64-bit counts, contiguous, once.  parts == 0: k_log_direct adds entry by entry
 // (tables so large that a batch touches few of their ranges).
 constexpr uint32_t kLogMany = 1024 + 256;   // pairs a workgroup can leave: aggregator + key cache entries (vf_kernels.hip)
-constexpr uint32_t kLogMaxParts = 256;
+#ifndef VF_LOG_MAX_PARTS
+#define VF_LOG_MAX_PARTS 256
+#endif
+constexpr uint32_t kLogMaxParts = VF_LOG_MAX_PARTS;     // (a power of two, at most the workgroup size)
 constexpr uint32_t kLogRange = 8192;        // slots per workgroup of k_log_apply (32 KiB of LDS counters)
 struct CountLog {
     uint32_t *one, *n_one;

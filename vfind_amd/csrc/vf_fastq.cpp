@@ -31,6 +31,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <stdexcept>
+#include <functional>
 #include <cerrno>
 #include <condition_variable>
 #include <cstdio>
@@ -461,7 +463,9 @@ static int frame_records(const uint8_t *t, size_t n, std::vector<ReadRef> &out, 
 
 }  // namespace
 
-extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
+static int vf_run_fastq_impl(vf_ctx *c, const char *path);
+extern "C" int vf_run_fastq(vf_ctx *c, const char *path) { return vf_guard([&] { return vf_run_fastq_impl(c, path); }); }
+static int vf_run_fastq_impl(vf_ctx *c, const char *path) {
     if (!c || !path) return vf_internal_fail(VF_EINVAL, "null argument");
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return vf_internal_fail(VF_EIO, std::string(path) + ": " + strerror(errno));
@@ -516,8 +520,34 @@ extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
     auto env_u = [](const char *k, uint32_t dflt) { const char *e = getenv(k); const int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : dflt; };
     const uint32_t ninfl = env_u("VFIND_FASTQ_INFLATERS", nthreads);
     const uint32_t npack = env_u("VFIND_FASTQ_PACKERS", device_framing ? std::max<uint32_t>(1, (nthreads + 3) / 4) : std::max<uint32_t>(1, (nthreads + 1) / 2));
+    std::vector<std::thread> inflaters;
+    std::atomic<bool> watch_stop{false};
+    std::thread watchdog;
+    // An exception on this thread (the sequencer allocates) must not unwind past running workers: a joinable std::thread
+    // that is destroyed ends the process.  Whatever way this function is left, the workers are told to stop and joined.
+    struct JoinAll {
+        std::function<void()> f;
+        ~JoinAll() { if (f) f(); }
+    } join_all;
+    join_all.f = [&] {
+        { std::lock_guard<std::mutex> g(R.mu); R.stop = true; for (auto &kv : R.tasks) kv.second->abort = true; }
+        R.cv.notify_all();
+        for (auto &th : inflaters) if (th.joinable()) th.join();
+        watch_stop = true;
+        if (watchdog.joinable()) watchdog.join();
+        chunks.close(true);
+        for (auto &th : packers) if (th.joinable()) th.join();
+    };
+    // a worker that throws (std::bad_alloc from a buffer, anything else from below) fails the run, it does not end the process
+    auto guarded = [&](auto &&body) {
+        try { body(); }
+        catch (const std::bad_alloc &) { fail_async(VF_ENOMEM, "out of host memory in a FASTQ worker thread"); }
+        catch (const std::exception &e) { fail_async(VF_EDEVICE, std::string("internal error in a FASTQ worker thread: ") + e.what()); }
+        catch (...) { fail_async(VF_EDEVICE, "internal error in a FASTQ worker thread"); }
+    };
     for (uint32_t w = 0; w < npack; ++w) {
-        packers.emplace_back([&] {
+        packers.emplace_back([&] { guarded([&] {
+            if (vf_internal_test_throw("fastq_worker")) throw std::runtime_error("injected by VFIND_TEST_THROW");
             std::vector<ReadRef> refs;
             std::unique_ptr<Chunk> ch;
             while (chunks.get(ch)) {
@@ -550,7 +580,7 @@ extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
                 }
                 if (rc) { fail_async(rc, err); break; }
             }
-        });
+        }); });
     }
 
     // ---- inflate pool --------------------------------------------------------------------------
@@ -558,11 +588,8 @@ extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
         std::lock_guard<std::mutex> g(R.mu);
         R.required = 0;
     }
-    std::vector<std::thread> inflaters;
-    for (uint32_t w = 0; w < ninfl; ++w) inflaters.emplace_back([&] { inflate_worker(R); });
+    for (uint32_t w = 0; w < ninfl; ++w) inflaters.emplace_back([&] { guarded([&] { inflate_worker(R); }); });
 
-    std::atomic<bool> watch_stop{false};
-    std::thread watchdog;
     if (g_dbg) watchdog = std::thread([&] {
         while (!watch_stop.load()) {
             for (int i = 0; i < 20 && !watch_stop.load(); ++i) usleep(100000);
@@ -716,5 +743,6 @@ extern "C" int vf_run_fastq(vf_ctx *c, const char *path) {
     if (watchdog.joinable()) watchdog.join();
     chunks.close(false);
     for (auto &th : packers) th.join();
+    join_all.f = nullptr;                      // everything is joined
     return vf_sync(c);
 }

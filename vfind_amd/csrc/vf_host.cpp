@@ -49,6 +49,14 @@ static int fail(int code, const std::string &msg) {
     } while (0)
 
 extern "C" const char *vf_last_error(void) { return g_err.c_str(); }
+int vf_internal_fail_noexcept(int code, const char *msg) noexcept {
+    try { g_err = msg; } catch (...) { g_err.clear(); }      // (assigning a short literal does not allocate: SSO)
+    return code;
+}
+bool vf_internal_test_throw(const char *where) {
+    const char *e = getenv("VFIND_TEST_THROW");
+    return e && strcmp(e, where) == 0;
+}
 extern "C" int vf_abi_version(void) { return VF_ABI_VERSION; }
 
 // base code of an adapter letter (the adapter was checked to be ACGT-only before this is used)
@@ -411,7 +419,9 @@ static int table_make_spare(vf_ctx *c) {
     return VF_OK;
 }
 
-extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
+static int vf_ctx_create_impl(const vf_params *p, vf_ctx **out);
+extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) { return vf_guard([&] { return vf_ctx_create_impl(p, out); }); }
+static int vf_ctx_create_impl(const vf_params *p, vf_ctx **out) {
     if (!p || !out) return fail(VF_EINVAL, "null argument");
     *out = nullptr;
     if ((p->prefix_len && !p->prefix) || (p->suffix_len && !p->suffix)) return fail(VF_EINVAL, "null adapter");
@@ -517,7 +527,11 @@ extern "C" int vf_ctx_create(const vf_params *p, vf_ctx **out) {
     return VF_OK;
 }
 
+static void vf_ctx_destroy_impl(vf_ctx *c);
 extern "C" void vf_ctx_destroy(vf_ctx *c) {
+    try { vf_ctx_destroy_impl(c); } catch (...) { }
+}
+static void vf_ctx_destroy_impl(vf_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->dev);
     (void)hipDeviceSynchronize();
@@ -955,7 +969,9 @@ static int to_refs(const uint64_t *offsets, uint64_t n, std::vector<ReadRef> &ou
     return VF_OK;
 }
 
-extern "C" int vf_submit_ascii(vf_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uint64_t n_reads) {
+static int vf_submit_ascii_impl(vf_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uint64_t n_reads);
+extern "C" int vf_submit_ascii(vf_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uint64_t n_reads) { return vf_guard([&] { return vf_submit_ascii_impl(c, bytes, offsets, n_reads); }); }
+static int vf_submit_ascii_impl(vf_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uint64_t n_reads) {
     if (!c || (n_reads && (!offsets || (!bytes && offsets[n_reads] != 0)))) return fail(VF_EINVAL, "null argument");
     std::vector<ReadRef> refs;
     int rc = to_refs(offsets, n_reads, refs);
@@ -963,7 +979,9 @@ extern "C" int vf_submit_ascii(vf_ctx *c, const uint8_t *bytes, const uint64_t *
     return submit_reads(c, bytes, refs.data(), n_reads, nullptr, nullptr);
 }
 
-extern "C" int vf_spans_ascii(vf_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uint64_t n_reads, int32_t *starts, int32_t *ends) {
+static int vf_spans_ascii_impl(vf_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uint64_t n_reads, int32_t *starts, int32_t *ends);
+extern "C" int vf_spans_ascii(vf_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uint64_t n_reads, int32_t *starts, int32_t *ends) { return vf_guard([&] { return vf_spans_ascii_impl(c, bytes, offsets, n_reads, starts, ends); }); }
+static int vf_spans_ascii_impl(vf_ctx *c, const uint8_t *bytes, const uint64_t *offsets, uint64_t n_reads, int32_t *starts, int32_t *ends) {
     if (!c || !starts || !ends || (n_reads && !offsets)) return fail(VF_EINVAL, "null argument");
     std::vector<ReadRef> refs;
     int rc = to_refs(offsets, n_reads, refs);
@@ -971,7 +989,9 @@ extern "C" int vf_spans_ascii(vf_ctx *c, const uint8_t *bytes, const uint64_t *o
     return submit_reads(c, bytes, refs.data(), n_reads, starts, ends);
 }
 
-extern "C" int vf_submit_packed(vf_ctx *c, const uint32_t *rows, uint32_t W, const uint16_t *lens, uint64_t n) {
+static int vf_submit_packed_impl(vf_ctx *c, const uint32_t *rows, uint32_t W, const uint16_t *lens, uint64_t n);
+extern "C" int vf_submit_packed(vf_ctx *c, const uint32_t *rows, uint32_t W, const uint16_t *lens, uint64_t n) { return vf_guard([&] { return vf_submit_packed_impl(c, rows, W, lens, n); }); }
+static int vf_submit_packed_impl(vf_ctx *c, const uint32_t *rows, uint32_t W, const uint16_t *lens, uint64_t n) {
     if (!c || (n && (!rows || !lens))) return fail(VF_EINVAL, "null argument");
     if (!c->fast_ok) return fail(VF_EINVAL, "these adapters/scores need the byte-wise path: use vf_submit_ascii");
     if (W != 10 && W != 20 && W != 40) return fail(VF_EINVAL, "row_dwords must be 10, 20 or 40");
@@ -1019,7 +1039,9 @@ extern "C" int vf_submit_packed(vf_ctx *c, const uint32_t *rows, uint32_t W, con
 // pinned packed-base buffers and streamed to HBM via hipMemcpyAsync overlapped with the previous batch").
 // vf_submit_packed takes ordinary host memory and has to copy it into that staging first: 22 GB/s instead of the link's rate.
 // ------------------------------------------------------------------------------------------------
-extern "C" int vf_batch_acquire(vf_ctx *c, uint64_t n_reads, uint32_t W, vf_batch **out, uint32_t **rows, uint16_t **lens) {
+static int vf_batch_acquire_impl(vf_ctx *c, uint64_t n_reads, uint32_t W, vf_batch **out, uint32_t **rows, uint16_t **lens);
+extern "C" int vf_batch_acquire(vf_ctx *c, uint64_t n_reads, uint32_t W, vf_batch **out, uint32_t **rows, uint16_t **lens) { return vf_guard([&] { return vf_batch_acquire_impl(c, n_reads, W, out, rows, lens); }); }
+static int vf_batch_acquire_impl(vf_ctx *c, uint64_t n_reads, uint32_t W, vf_batch **out, uint32_t **rows, uint16_t **lens) {
     if (!c || !out || !rows || !lens) return fail(VF_EINVAL, "null argument");
     *out = nullptr;
     if (!c->fast_ok) return fail(VF_EINVAL, "these adapters/scores need the byte-wise path: use vf_submit_ascii");
@@ -1034,14 +1056,18 @@ extern "C" int vf_batch_acquire(vf_ctx *c, uint64_t n_reads, uint32_t W, vf_batc
     *out = reinterpret_cast<vf_batch *>(s);
     return VF_OK;
 }
-extern "C" int vf_batch_release(vf_ctx *c, vf_batch *b) {
+static int vf_batch_release_impl(vf_ctx *c, vf_batch *b);
+extern "C" int vf_batch_release(vf_ctx *c, vf_batch *b) { return vf_guard([&] { return vf_batch_release_impl(c, b); }); }
+static int vf_batch_release_impl(vf_ctx *c, vf_batch *b) {
     if (!c || !b) return fail(VF_EINVAL, "null argument");
     Slot *s = reinterpret_cast<Slot *>(b);
     s->batch_cap = 0;
     release_slot(c, s);
     return VF_OK;
 }
-extern "C" int vf_batch_submit(vf_ctx *c, vf_batch *b, uint64_t n) {
+static int vf_batch_submit_impl(vf_ctx *c, vf_batch *b, uint64_t n);
+extern "C" int vf_batch_submit(vf_ctx *c, vf_batch *b, uint64_t n) { return vf_guard([&] { return vf_batch_submit_impl(c, b, n); }); }
+static int vf_batch_submit_impl(vf_ctx *c, vf_batch *b, uint64_t n) {
     if (!c || !b) return fail(VF_EINVAL, "null argument");
     Slot *s = reinterpret_cast<Slot *>(b);
     struct Rel { vf_ctx *c; Slot *s; ~Rel() { s->batch_cap = 0; release_slot(c, s); } } rel{c, s};
@@ -1068,7 +1094,9 @@ extern "C" int vf_batch_submit(vf_ctx *c, vf_batch *b, uint64_t n) {
     return VF_OK;
 }
 
-extern "C" int vf_process_device_packed(vf_ctx *c, const void *d_rows, uint32_t W, const void *d_lens, uint64_t n, void *d_spans) {
+static int vf_process_device_packed_impl(vf_ctx *c, const void *d_rows, uint32_t W, const void *d_lens, uint64_t n, void *d_spans);
+extern "C" int vf_process_device_packed(vf_ctx *c, const void *d_rows, uint32_t W, const void *d_lens, uint64_t n, void *d_spans) { return vf_guard([&] { return vf_process_device_packed_impl(c, d_rows, W, d_lens, n, d_spans); }); }
+static int vf_process_device_packed_impl(vf_ctx *c, const void *d_rows, uint32_t W, const void *d_lens, uint64_t n, void *d_spans) {
     if (!c || (n && (!d_rows || !d_lens))) return fail(VF_EINVAL, "null argument");
     if (!c->fast_ok) return fail(VF_EINVAL, "these adapters/scores need the byte-wise path: use vf_submit_ascii");
     if (W != 10 && W != 20 && W != 40) return fail(VF_EINVAL, "row_dwords must be 10, 20 or 40");
@@ -1110,10 +1138,13 @@ static int check_device_errors(vf_ctx *c, uint64_t *counters_out) {
     if (h[C_ERROR] & 2) return fail(VF_ECAPACITY, "device count table full: raise table_slots");
     if (h[C_ERROR] & 4) return fail(VF_ECAPACITY, "a variant region exceeds 65535 symbols");
     if (h[C_ERROR] & 8) return fail(VF_EDEVICE, "count log: part totals and entries disagree (internal error)");
+    if (h[C_ERROR] & 16) return fail(VF_EDEVICE, "key cache: occurrences of a key whose insert failed (internal error)");
     return VF_OK;
 }
 
-extern "C" int vf_sync(vf_ctx *c) {
+static int vf_sync_impl(vf_ctx *c);
+extern "C" int vf_sync(vf_ctx *c) { return vf_guard([&] { return vf_sync_impl(c); }); }
+static int vf_sync_impl(vf_ctx *c) {
     if (!c) return fail(VF_EINVAL, "null context");
     HIP_TRY(hipSetDevice(c->dev));
     {
@@ -1145,7 +1176,9 @@ extern "C" int vf_sync(vf_ctx *c) {
 // ------------------------------------------------------------------------------------------------
 // Asynchronous: ordered after every batch already submitted (device-side event waits) and before
 // everything submitted afterwards; the host does not block.
-extern "C" int vf_table_clear(vf_ctx *c) {
+static int vf_table_clear_impl(vf_ctx *c);
+extern "C" int vf_table_clear(vf_ctx *c) { return vf_guard([&] { return vf_table_clear_impl(c); }); }
+static int vf_table_clear_impl(vf_ctx *c) {
     if (!c) return fail(VF_EINVAL, "null context");
     HIP_TRY(hipSetDevice(c->dev));
     for (auto &s : c->slots)
@@ -1174,7 +1207,9 @@ extern "C" int vf_table_clear(vf_ctx *c) {
 
 static uint64_t blob_bytes(uint64_t n, uint64_t arena_dw) { return 16 + n * 16 + arena_dw * 4; }
 
-extern "C" int vf_table_export_size(vf_ctx *c, uint64_t *nbytes) {
+static int vf_table_export_size_impl(vf_ctx *c, uint64_t *nbytes);
+extern "C" int vf_table_export_size(vf_ctx *c, uint64_t *nbytes) { return vf_guard([&] { return vf_table_export_size_impl(c, nbytes); }); }
+static int vf_table_export_size_impl(vf_ctx *c, uint64_t *nbytes) {
     if (!c || !nbytes) return fail(VF_EINVAL, "null argument");
     int rc = vf_sync(c);
     if (rc) return rc;
@@ -1202,7 +1237,9 @@ static int export_blob(vf_ctx *c, uint32_t G, uint32_t owner, uint64_t n, uint64
     return VF_OK;
 }
 
-extern "C" int vf_table_export(vf_ctx *c, void *d_dst, uint64_t capacity, uint64_t *written) {
+static int vf_table_export_impl(vf_ctx *c, void *d_dst, uint64_t capacity, uint64_t *written);
+extern "C" int vf_table_export(vf_ctx *c, void *d_dst, uint64_t capacity, uint64_t *written) { return vf_guard([&] { return vf_table_export_impl(c, d_dst, capacity, written); }); }
+static int vf_table_export_impl(vf_ctx *c, void *d_dst, uint64_t capacity, uint64_t *written) {
     if (!c || !d_dst) return fail(VF_EINVAL, "null argument");
     int rc = vf_sync(c);
     if (rc) return rc;
@@ -1226,7 +1263,9 @@ static int partition_counts(vf_ctx *c, uint32_t world) {
     c->part_world = world;
     return VF_OK;
 }
-extern "C" int vf_table_partition_sizes(vf_ctx *c, uint32_t world, uint64_t *nbytes) {
+static int vf_table_partition_sizes_impl(vf_ctx *c, uint32_t world, uint64_t *nbytes);
+extern "C" int vf_table_partition_sizes(vf_ctx *c, uint32_t world, uint64_t *nbytes) { return vf_guard([&] { return vf_table_partition_sizes_impl(c, world, nbytes); }); }
+static int vf_table_partition_sizes_impl(vf_ctx *c, uint32_t world, uint64_t *nbytes) {
     if (!c || !nbytes) return fail(VF_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(c->dev));
     int rc = partition_counts(c, world);
@@ -1234,7 +1273,9 @@ extern "C" int vf_table_partition_sizes(vf_ctx *c, uint32_t world, uint64_t *nby
     for (uint32_t o = 0; o < world; ++o) nbytes[o] = blob_bytes(c->part[2 * o], c->part[2 * o + 1]);
     return VF_OK;
 }
-extern "C" int vf_table_partition_export(vf_ctx *c, uint32_t world, uint32_t owner, void *d_dst, uint64_t capacity, uint64_t *written) {
+static int vf_table_partition_export_impl(vf_ctx *c, uint32_t world, uint32_t owner, void *d_dst, uint64_t capacity, uint64_t *written);
+extern "C" int vf_table_partition_export(vf_ctx *c, uint32_t world, uint32_t owner, void *d_dst, uint64_t capacity, uint64_t *written) { return vf_guard([&] { return vf_table_partition_export_impl(c, world, owner, d_dst, capacity, written); }); }
+static int vf_table_partition_export_impl(vf_ctx *c, uint32_t world, uint32_t owner, void *d_dst, uint64_t capacity, uint64_t *written) {
     if (!c || !d_dst) return fail(VF_EINVAL, "null argument");
     if (world == 0 || owner >= world) return fail(VF_EINVAL, "owner out of range");
     HIP_TRY(hipSetDevice(c->dev));
@@ -1250,7 +1291,9 @@ static int blob_header_ok(const uint64_t hdr[2], uint64_t nbytes) {
     return VF_OK;
 }
 
-extern "C" int vf_table_merge(vf_ctx *c, const void *d_blob, uint64_t nbytes) {
+static int vf_table_merge_impl(vf_ctx *c, const void *d_blob, uint64_t nbytes);
+extern "C" int vf_table_merge(vf_ctx *c, const void *d_blob, uint64_t nbytes) { return vf_guard([&] { return vf_table_merge_impl(c, d_blob, nbytes); }); }
+static int vf_table_merge_impl(vf_ctx *c, const void *d_blob, uint64_t nbytes) {
     if (!c || !d_blob) return fail(VF_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(c->dev));
     if (nbytes < 16) return fail(VF_EINVAL, "blob too small");
@@ -1329,7 +1372,9 @@ static void vf_comm_release(vf_ctx *c) {
     c->comm_rank = 0; c->comm_world = 1;
 }
 
-extern "C" int vf_comm_unique_id(void *id128) {
+static int vf_comm_unique_id_impl(void *id128);
+extern "C" int vf_comm_unique_id(void *id128) { return vf_guard([&] { return vf_comm_unique_id_impl(id128); }); }
+static int vf_comm_unique_id_impl(void *id128) {
     if (!id128) return fail(VF_EINVAL, "null argument");
     Rccl *R = rccl();
     if (!R) return fail(VF_EDEVICE, "librccl.so.1 is not loadable");
@@ -1340,7 +1385,9 @@ extern "C" int vf_comm_unique_id(void *id128) {
     return VF_OK;
 }
 
-extern "C" int vf_comm_init(vf_ctx *c, int rank, int world, const void *id128) {
+static int vf_comm_init_impl(vf_ctx *c, int rank, int world, const void *id128);
+extern "C" int vf_comm_init(vf_ctx *c, int rank, int world, const void *id128) { return vf_guard([&] { return vf_comm_init_impl(c, rank, world, id128); }); }
+static int vf_comm_init_impl(vf_ctx *c, int rank, int world, const void *id128) {
     if (!c || !id128) return fail(VF_EINVAL, "null argument");
     if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(VF_EINVAL, "rank / world out of range (1..64 GPUs)");
     Rccl *R = rccl();
@@ -1362,7 +1409,9 @@ extern "C" int vf_comm_init(vf_ctx *c, int rank, int world, const void *id128) {
 //   3. every owner empties its table and merges its own bucket and the world - 1 it received: its share, fully summed;
 //   4. the shares -- disjoint key sets -- go to `root` (sizes by ncclAllGather, one grouped exchange), which merges them.
 // Afterwards root's table is the sum of all tables; every other rank is left holding its own share.
-extern "C" int vf_table_allreduce(vf_ctx *c, int root) {
+static int vf_table_allreduce_impl(vf_ctx *c, int root);
+extern "C" int vf_table_allreduce(vf_ctx *c, int root) { return vf_guard([&] { return vf_table_allreduce_impl(c, root); }); }
+static int vf_table_allreduce_impl(vf_ctx *c, int root) {
     if (!c) return fail(VF_EINVAL, "null context");
     const int G = c->comm_world, me = c->comm_rank;
     if (G == 1) return VF_OK;
@@ -1435,7 +1484,11 @@ extern "C" int vf_table_allreduce(vf_ctx *c, int root) {
     return VF_OK;
 }
 
-extern "C" int vf_finish(vf_ctx *c, vf_result **out) {
+static int vf_finish_impl(vf_ctx *c, vf_result **out);
+extern "C" int vf_finish(vf_ctx *c, vf_result **out) { return vf_guard([&] { return vf_finish_impl(c, out); }); }
+static int vf_finish_impl(vf_ctx *c, vf_result **out) {
+    if (vf_internal_test_throw("finish")) throw std::bad_alloc();
+    if (vf_internal_test_throw("finish_length")) { std::vector<uint64_t> v; v.resize((size_t)-1 / 2); }     // std::length_error
     if (!c || !out) return fail(VF_EINVAL, "null argument");
     *out = nullptr;
     uint64_t nbytes = 0;
@@ -1466,7 +1519,9 @@ extern "C" int vf_finish(vf_ctx *c, vf_result **out) {
 // The frame of several exported tables at once (the tables of several GPUs gathered on one device, or the shares of an
 // owner-partitioned exchange): laid end to end and handed to the device result build, which sums equal strings -- no merge
 // into a count table in between.
-extern "C" int vf_finish_blobs(vf_ctx *c, const void *const *d_blobs, const uint64_t *nbytes, uint32_t n_blobs, vf_result **out) {
+static int vf_finish_blobs_impl(vf_ctx *c, const void *const *d_blobs, const uint64_t *nbytes, uint32_t n_blobs, vf_result **out);
+extern "C" int vf_finish_blobs(vf_ctx *c, const void *const *d_blobs, const uint64_t *nbytes, uint32_t n_blobs, vf_result **out) { return vf_guard([&] { return vf_finish_blobs_impl(c, d_blobs, nbytes, n_blobs, out); }); }
+static int vf_finish_blobs_impl(vf_ctx *c, const void *const *d_blobs, const uint64_t *nbytes, uint32_t n_blobs, vf_result **out) {
     if (!c || !out || (n_blobs && (!d_blobs || !nbytes))) return fail(VF_EINVAL, "null argument");
     *out = nullptr;
     HIP_TRY(hipSetDevice(c->dev));
@@ -1514,7 +1569,9 @@ extern "C" void vf_result_free(vf_result *r) { delete r; }
 // ------------------------------------------------------------------------------------------------
 // stats
 // ------------------------------------------------------------------------------------------------
-extern "C" int vf_stats_get(vf_ctx *c, vf_stats *o) {
+static int vf_stats_get_impl(vf_ctx *c, vf_stats *o);
+extern "C" int vf_stats_get(vf_ctx *c, vf_stats *o) { return vf_guard([&] { return vf_stats_get_impl(c, o); }); }
+static int vf_stats_get_impl(vf_ctx *c, vf_stats *o) {
     if (!c || !o) return fail(VF_EINVAL, "null argument");
     int rc = vf_sync(c);
     if (rc && rc != VF_ECAPACITY) return rc;
@@ -1540,7 +1597,9 @@ extern "C" int vf_stats_get(vf_ctx *c, vf_stats *o) {
     o->ms_count_log = c->ms[K_LOG]; o->launches_count_log = c->launches[K_LOG];
     return VF_OK;
 }
-extern "C" int vf_stats_reset(vf_ctx *c) {
+static int vf_stats_reset_impl(vf_ctx *c);
+extern "C" int vf_stats_reset(vf_ctx *c) { return vf_guard([&] { return vf_stats_reset_impl(c); }); }
+static int vf_stats_reset_impl(vf_ctx *c) {
     if (!c) return fail(VF_EINVAL, "null context");
     int rc = vf_sync(c);
     if (rc && rc != VF_ECAPACITY) return rc;
@@ -1557,7 +1616,9 @@ extern "C" int vf_stats_reset(vf_ctx *c) {
     }
     return VF_OK;
 }
-extern "C" int vf_set_profiling(vf_ctx *c, int on) {
+static int vf_set_profiling_impl(vf_ctx *c, int on);
+extern "C" int vf_set_profiling(vf_ctx *c, int on) { return vf_guard([&] { return vf_set_profiling_impl(c, on); }); }
+static int vf_set_profiling_impl(vf_ctx *c, int on) {
     if (!c) return fail(VF_EINVAL, "null context");
     c->profiling = on == 2 ? 2 : (on != 0 ? 1 : 0);
     return VF_OK;

@@ -3,6 +3,8 @@
 #include <stdint.h>
 
 #include <memory>
+#include <new>
+#include <exception>
 #include <string>
 #include <utility>
 #include <vector>
@@ -23,6 +25,23 @@ void vf_internal_set_async_error(vf_ctx *c, int rc, const std::string &msg);
 uint32_t vf_internal_threads(const vf_ctx *c);
 int vf_internal_fail(int code, const std::string &msg);      // sets the calling thread's error text
 std::string vf_internal_last_error();
+int vf_internal_fail_noexcept(int code, const char *msg) noexcept;   // the same for a message that must not allocate
+
+// The exception barrier of the C ABI (include/vfind_hip.h: "no exceptions or panics cross the ABI"): every extern "C" entry
+// point runs its body inside vf_guard, so a std::bad_alloc or a length_error from a vector sized by a device-read value
+// comes back as an error code and a message, never as std::terminate in the host process - what lib.rs:317 does with a
+// failed frame build (PyValueError) and what lib.rs:155, 308 do not (unwrap -> panic).
+template <class F> static inline int vf_guard(F &&f) noexcept {
+    try { return f(); }
+    catch (const std::bad_alloc &) { return vf_internal_fail_noexcept(6 /* VF_ENOMEM */, "out of host memory"); }
+    catch (const std::exception &e) {
+        try { return vf_internal_fail(4 /* VF_EDEVICE */, std::string("internal error: ") + e.what()); }
+        catch (...) { return vf_internal_fail_noexcept(4, "internal error"); }
+    }
+    catch (...) { return vf_internal_fail_noexcept(4, "internal error: unknown exception"); }
+}
+// test hook: VFIND_TEST_THROW=<where> makes the named place throw (tests/test_gpu_parity.py::test_exception_barrier...)
+bool vf_internal_test_throw(const char *where);
 
 // the (sequence, count) frame handed over the ABI (lib.rs:312-319): rows sorted count desc, sequence asc
 // (vector storage that resize() leaves uninitialised: the buffers are filled by a device-to-host copy, and zeroing 600 MB

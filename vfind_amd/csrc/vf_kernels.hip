@@ -1563,11 +1563,11 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
     // finds a slot claimed but not yet published simply looks again on the next trip; because the
     // claiming lane (possibly in this very wave) publishes inside the loop body, before the vote,
     // the wait cannot deadlock and the compiler cannot sink the publish past the loop exit.
-#ifdef VF_FINISH_ABLATION
+#ifdef VF_INSERT_COUNTERS
     if (lane_id() == 0) atomicAdd((unsigned long long *)&t.counters[C_DBG0], 1ull);
 #endif
     while (__any(!done)) {
-#ifdef VF_FINISH_ABLATION
+#ifdef VF_INSERT_COUNTERS
         if (lane_id() == 0) atomicAdd((unsigned long long *)&t.counters[C_DBG1], 1ull);
 #endif
         if (!done) {
@@ -1581,7 +1581,7 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
                 if (w0 == 0ull) {
                     w0 = atomicCAS(reinterpret_cast<unsigned long long *>(sp), 0ull, (unsigned long long)w0claim);
                     claimed = w0 == 0ull;
-#ifdef VF_FINISH_ABLATION
+#ifdef VF_INSERT_COUNTERS
                     atomicAdd((unsigned long long *)&t.counters[C_DBG2], 1ull);
                     if (claimed) atomicAdd((unsigned long long *)&t.counters[C_DBG3], 1ull);
 #endif
@@ -1732,14 +1732,20 @@ __device__ __forceinline__ void agg_flush(Agg &a, const CountLog &log, uint32_t 
         if (a.slot[i] != kNoSlot && a.cnt[i]) log_many(log, s_tot, s_nmany, a.slot[i], a.cnt[i]);
 }
 
-// Workgroup-level key cache: the keys the workgroup has already found in the table, whole, in LDS.  A read whose key sits
-// here is counted without touching the table at all.  What it saves is not HBM traffic (a hot slot line never leaves
-// the XCD's L2) but requests to ONE line: the first key of the Zipf stream is 12 % of the reads, the first ten a third,
-// and every lookup of a key is two or three 16-byte requests to the same L2 line from every CU of the XCD, served one
-// after the other by that line's channel.  Entry = 16 dwords:
-//   { state, h1, h2, meta | slot, count, -, - | key[0..3] | key[4..7] }     state 0 empty, 1 being filled, 2 ready
-// direct mapped by h1; filled by the lane that first finds the key in the table (fast path) while the entry is empty,
-// never replaced; keys of more than eight dwords are not cached.  Flushed like the aggregator at kernel end.
+// Workgroup-level key cache: the occurrences of a workgroup's commonest keys, counted in LDS by key, in front of the table.
+// The first lane of the workgroup that meets a key while the key's entry is free claims the entry, then takes the table
+// path itself (lookup, insert queue) and publishes the slot it ends up with; every later read of that key in the
+// workgroup - in the same wave a moment later, or ten thousand reads on - is counted in the entry and asks the table
+// nothing.  What it saves is requests to ONE line: the first key of the Zipf stream is 12 % of the reads, the first ten
+// a third, and every table lookup of a key is two or three 16-byte requests to the same L2 line from every CU of the
+// XCD, served one after the other by that line's channel.  In a cleared table that was the launch's first 100 us: every
+// wave's first insert batch held eight lanes of the commonest key and all 3 072 waves ran it at once (rounds 1-2 entered
+// a key only once the table had it, i.e. after that storm).  Entry = 16 dwords:
+//   { state, h1, h2, meta | slot, count, -, - | key[0..3] | key[4..7] }
+//   state 0 free, 1 claimed (key and tags written by the claiming lane right after the claim; slot not yet known),
+//   2 slot known.  Tags are written after the key words and a wave's LDS operations execute in order, so a reader that
+//   sees matching tags sees the whole key; an entry is never replaced; meta is never 0 (a counted key has a length).
+// Direct mapped by h1; keys of more than eight dwords are not cached.  Flushed at kernel end as (slot, count) pairs.
 #ifndef VF_KEYCACHE_SIZE
 #define VF_KEYCACHE_SIZE 256
 #endif
@@ -1752,40 +1758,56 @@ __device__ __forceinline__ void keycache_init(KeyCache &kc) {
     }
 }
 __device__ __forceinline__ uint32_t keycache_index(uint32_t h1) { return ((h1 * 0x9E3779B1u) >> 16) & (uint32_t)(kKeyCacheSize - 1); }
-// true = the key is cached and has been counted there
-__device__ __forceinline__ bool keycache_hit(KeyCache &kc, uint32_t h1, uint32_t h2, uint32_t meta, const uint32_t (&kin)[kInlineDwords], bool can) {
-    if (!can) return false;
-    const uint32_t i = keycache_index(h1);
+__device__ __forceinline__ bool keycache_match(KeyCache &kc, uint32_t i, uint32_t h1, uint32_t h2, uint32_t meta, const uint32_t (&kin)[kInlineDwords]) {
+    // volatile: the compiler keeps the LDS reads in program order (tags, then key words)
     const u32x4 t0 = *(volatile u32x4 *)&kc.q[i][0];
-    if (t0.x != 2u || t0.y != h1 || t0.z != h2 || t0.w != meta) return false;
-    // volatile like the state word: the compiler keeps the three LDS reads in program order and a wave's LDS operations
-    // execute in order, so the key words are read after the state said "ready" (a fence here would also wait for the
-    // row prefetch in flight)
+    if (t0.x == 0u || t0.y != h1 || t0.z != h2 || t0.w != meta) return false;
     const u32x4 k0 = *(volatile u32x4 *)&kc.q[i][2], k1 = *(volatile u32x4 *)&kc.q[i][3];
     const uint32_t diff = (k0.x ^ kin[0]) | (k0.y ^ kin[1]) | (k0.z ^ kin[2]) | (k0.w ^ kin[3]) |
                           (k1.x ^ kin[4]) | (k1.y ^ kin[5]) | (k1.z ^ kin[6]) | (k1.w ^ kin[7]);
-    if (diff != 0u) return false;
-    atomicAdd(reinterpret_cast<uint32_t *>(&kc.q[i][1]) + 1, 1u);
-    return true;
+    return diff == 0u;
 }
-// a key just found in the table at `slot` (not yet counted): true = entered into the cache with count 1
-__device__ __forceinline__ bool keycache_fill(KeyCache &kc, uint32_t h1, uint32_t h2, uint32_t meta, const uint32_t (&kin)[kInlineDwords], uint32_t slot) {
+// What the cache does with one read of a key: kCacheCounted = counted in the key's entry, done; kCacheOwner = this lane
+// has just claimed the entry for the key: it goes on to the table (where its own occurrence is counted like any other) and
+// publishes the slot; kCacheNone = the entry belongs to another key (or the key is not cacheable): table path.
+enum { kCacheNone = 0, kCacheCounted = 1, kCacheOwner = 2 };
+__device__ __forceinline__ int keycache_probe(KeyCache &kc, uint32_t h1, uint32_t h2, uint32_t meta, const uint32_t (&kin)[kInlineDwords], bool can) {
     const uint32_t i = keycache_index(h1);
     uint32_t *st = reinterpret_cast<uint32_t *>(&kc.q[i][0]);
-    if (*(volatile uint32_t *)st != 0u) return false;
-    if (atomicCAS(st, 0u, 1u) != 0u) return false;
-    kc.q[i][2] = u32x4{kin[0], kin[1], kin[2], kin[3]};
-    kc.q[i][3] = u32x4{kin[4], kin[5], kin[6], kin[7]};
-    kc.q[i][1] = u32x4{slot, 1u, 0u, 0u};
-    st[1] = h1; st[2] = h2; st[3] = meta;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    *(volatile uint32_t *)st = 2u;
-    return true;
+    int role = kCacheNone;
+    if (can && *(volatile uint32_t *)st == 0u && atomicCAS(st, 0u, 1u) == 0u) {
+        *(volatile u32x4 *)&kc.q[i][2] = u32x4{kin[0], kin[1], kin[2], kin[3]};
+        *(volatile u32x4 *)&kc.q[i][3] = u32x4{kin[4], kin[5], kin[6], kin[7]};
+        *(volatile u32x4 *)&kc.q[i][1] = u32x4{kNoSlot, 0u, 0u, 0u};
+        ((volatile uint32_t *)st)[1] = h1; ((volatile uint32_t *)st)[2] = h2; ((volatile uint32_t *)st)[3] = meta;
+        role = kCacheOwner;
+    }
+    // (the lanes of this wave that lost the claim to a lane with the same key find the key written: same instruction
+    // stream, LDS operations in order)
+    if (can && role == kCacheNone && keycache_match(kc, i, h1, h2, meta, kin)) {
+        atomicAdd(reinterpret_cast<uint32_t *>(&kc.q[i][1]) + 1, 1u);
+        role = kCacheCounted;
+    }
+    return role;
 }
-__device__ __forceinline__ void keycache_flush(KeyCache &kc, const CountLog &log, uint32_t *s_tot, uint32_t *s_nmany) {
+// the table slot of a key (found or inserted, by whichever lane of the workgroup got there): noted in the key's entry if
+// it has one that still waits for it.  Two lanes may both note a slot - each is a slot of that key (duplicates of a key
+// in the table are summed when the result is built), either will do.
+__device__ __forceinline__ void keycache_publish(KeyCache &kc, uint32_t h1, uint32_t h2, uint32_t meta, const uint32_t (&kin)[kInlineDwords], uint32_t slot, bool can) {
+    if (!can || slot == kNoSlot) return;
+    const uint32_t i = keycache_index(h1);
+    volatile uint32_t *st = reinterpret_cast<volatile uint32_t *>(&kc.q[i][0]);
+    if (st[0] != 1u || !keycache_match(kc, i, h1, h2, meta, kin)) return;
+    reinterpret_cast<volatile uint32_t *>(&kc.q[i][1])[0] = slot;
+    st[0] = 2u;
+}
+// after the workgroup's last table access.  An entry with occurrences but no slot means its owner's insert failed: the
+// table or the arena is full, which the insert has flagged; flagged again here so that it cannot pass unseen.
+__device__ __forceinline__ void keycache_flush(KeyCache &kc, const Table &t, const CountLog &log, uint32_t *s_tot, uint32_t *s_nmany) {
     for (int i = threadIdx.x; i < kKeyCacheSize; i += kBlock) {
         const u32x4 t0 = kc.q[i][0], t1 = kc.q[i][1];
         if (t0.x == 2u && t1.y) log_many(log, s_tot, s_nmany, t1.x, t1.y);
+        else if (t0.x == 1u && t1.y) atomicOr((unsigned long long *)&t.counters[C_ERROR], 16ull);
     }
 }
 
@@ -2041,13 +2063,15 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
                     n_act += (uint32_t)__popcll(__ballot(act[u]));
                 }
                 if (lane == 0) { atomicAdd(&s_stat[0], n_ok); atomicAdd(&s_stat[1], n_act); }
-                bool found[U], cached[U], inserted[U];
+                bool found[U], cached[U], inserted[U], owner[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     inserted[u] = false;
-                    cached[u] = VF_KEYCACHE && keycache_hit(kc, fp[u].h1, fp[u].h2, fp[u].meta, fp[u].kin, fp[u].can && fp[u].nd <= 8u);
+                    const int role = VF_KEYCACHE ? keycache_probe(kc, fp[u].h1, fp[u].h2, fp[u].meta, fp[u].kin, fp[u].can && fp[u].nd <= 8u) : (int)kCacheNone;
+                    cached[u] = role == kCacheCounted;
+                    owner[u] = role == kCacheOwner;
                     fp[u].can = fp[u].can && !cached[u];
-#ifdef VF_FINISH_ABLATION
+#ifdef VF_INSERT_COUNTERS
                     { const uint64_t mh = __ballot(cached[u]); if (mh && lane == 0) atomicAdd((unsigned long long *)&t.counters[C_DBG4], (unsigned long long)__popcll(mh)); }
 #endif
                 }
@@ -2094,10 +2118,8 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     bool to_log = false;
-                    if (found[u] && DBG != 3 && DBG != 4) {
-                        const bool entered = VF_KEYCACHE && fp[u].nd <= 8u && keycache_fill(kc, fp[u].h1, fp[u].h2, fp[u].meta, fp[u].kin, fp[u].slot);
-                        to_log = !entered && !agg_try(agg, fp[u].slot);
-                    }
+                    if (found[u] && DBG != 3 && DBG != 4) to_log = !agg_try(agg, fp[u].slot);
+                    if (VF_KEYCACHE && owner[u] && (found[u] || inserted[u])) keycache_publish(kc, fp[u].h1, fp[u].h2, fp[u].meta, fp[u].kin, fp[u].slot, true);
                     log_one(wl, log, s_tot, fp[u].slot, to_log);
                     const bool miss = act[u] && !found[u] && !cached[u] && !inserted[u];
                     const uint64_t m = __ballot(miss);
@@ -2140,6 +2162,11 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
             finish_key<W, DNA>(xs, sp.x, sp.y, oks, lut, ks, ls, as);
             bool counted;
             const uint32_t sl = table_find_or_insert(t, bt, RegKey<ND>{ks}, FK::kKind, ls, as, kNoOff, true, counted);
+            if (VF_KEYCACHE) {                  // the key's cache entry may be waiting for this slot
+                FastProbe fq;
+                fast_prepare<ND>(t, ks, FK::kKind, ls, as, fq);
+                keycache_publish(kc, fq.h1, fq.h2, fq.meta, fq.kin, sl, fq.can && fq.nd <= 8u);
+            }
             log_one(wl, log, s_tot, sl, sl != kNoSlot && !counted && !agg_try(agg, sl));
             nslow = base;
             __builtin_amdgcn_wave_barrier();
@@ -2155,7 +2182,7 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
     if (lane == 0) log.n_one[gwave] = wl.n < log.cap_one ? wl.n : log.cap_one;
     __syncthreads();
     agg_flush(agg, log, s_tot, &s_stat[3]);
-    keycache_flush(kc, log, s_tot, &s_stat[3]);
+    keycache_flush(kc, t, log, s_tot, &s_stat[3]);
     block_table_end(bt, t);
     __syncthreads();
     if (log.parts)
