@@ -196,7 +196,19 @@ int vf_table_partition_export(vf_ctx *ctx, uint32_t world, uint32_t owner, void 
  * loaded on first use. */
 int vf_comm_unique_id(void *id128);
 int vf_comm_init(vf_ctx *ctx, int rank, int world, const void *id128);
+/* On a local failure of one rank (no memory for a buffer, a table that cannot grow) every rank returns an error: the ranks
+ * exchange a status word before each round of transfers, nobody is left waiting for a peer that has gone. */
 int vf_table_allreduce(vf_ctx *ctx, int root);
+
+/* The same exchange between contexts of ONE process (one host thread per context, on one device or several): a group
+ * object is the rendezvous, bytes move by device-to-device copies.  For a host that drives all GPUs of a node from one
+ * process - and how the exchange code itself is run with world > 1 on a one-GPU box (RCCL refuses two ranks on one
+ * device).  Every context of the group calls vf_table_allreduce from its own thread; the group outlives its contexts'
+ * last call and is destroyed by the host. */
+typedef struct vf_local_group vf_local_group;
+int vf_comm_local_create(int world, vf_local_group **out);
+void vf_comm_local_destroy(vf_local_group *group);
+int vf_comm_init_local(vf_ctx *ctx, int rank, vf_local_group *group);
 
 int vf_stats_get(vf_ctx *ctx, vf_stats *out);
 int vf_stats_reset(vf_ctx *ctx);

@@ -73,6 +73,9 @@ extern "C" {
     pub fn vf_comm_unique_id(id128: *mut c_void) -> c_int;
     pub fn vf_comm_init(ctx: *mut VfCtx, rank: c_int, world: c_int, id128: *const c_void) -> c_int;
     pub fn vf_table_allreduce(ctx: *mut VfCtx, root: c_int) -> c_int;
+    pub fn vf_comm_local_create(world: c_int, out: *mut *mut c_void) -> c_int;
+    pub fn vf_comm_local_destroy(group: *mut c_void);
+    pub fn vf_comm_init_local(ctx: *mut VfCtx, rank: c_int, group: *mut c_void) -> c_int;
     pub fn vf_stats_get(ctx: *mut VfCtx, out: *mut VfStats) -> c_int;
     pub fn vf_stats_reset(ctx: *mut VfCtx) -> c_int;
     pub fn vf_set_profiling(ctx: *mut VfCtx, on: c_int) -> c_int;

@@ -917,6 +917,70 @@ def test_frame_from_several_exported_tables_sums_equal_strings():
         assert got == want and len(got) > 1000
 
 
+@pytest.mark.parametrize("world,root", [(2, 0), (3, 2), (8, 5)])
+def test_table_allreduce_between_local_contexts(world, root):
+    """vf_table_allreduce itself - bucket export, send / receive / gather offsets, the round of transfers, the share gather,
+    the merges - with world > 1: `world` contexts on this one device, one thread each, joined by the in-process transport
+    (RCCL refuses two ranks on one device; only the five transport calls differ from the RCCL path).  Root ends up with the
+    oracle's table of ALL reads, every other rank with its own share: disjoint key sets whose union is that table"""
+    from vfind_amd import Engine, LocalGroup
+    parts = [synth.make_reads(700 + r, 2500 + 300 * r, AD20, L=150, n_variants=600, sub=0.004, indel=0.0) for r in range(world)]
+    want = oracle.count([x for p in parts for x in p], AD20)
+    engines = [Engine(AD20, table_slots=1 << 12, arena_bytes=1 << 22) for _ in range(world)]      # (small tables: the merges must grow them)
+    try:
+        for e, p in zip(engines, parts):
+            e.submit(p)
+        g = LocalGroup(world)
+        errs = g.reduce(engines, root=root)
+        assert errs == [None] * world, errs
+        tables = [e.finish_dict() for e in engines]
+        assert tables[root] == want
+        seen = {}
+        for r, t in enumerate(tables):
+            if r == root:
+                continue
+            for k, v in t.items():
+                assert k not in seen, "shares overlap"
+                assert want[k] == v
+                seen[k] = v
+        # root's own share is the rest
+        assert set(seen) <= set(want)
+        # a second exchange on the same group (the rendezvous is reusable): root's table doubles for the keys it owned...
+        # just check that it completes and root still holds every key
+        errs = g.reduce(engines, root=root)
+        assert errs == [None] * world, errs
+        assert set(engines[root].finish_dict()) == set(want)
+        g.close()
+    finally:
+        for e in engines:
+            e.close()
+
+
+def test_table_allreduce_every_rank_leaves_when_one_fails(monkeypatch):
+    """a rank that fails locally between the collectives (round 2 returned early there and left its peers in a receive) says so
+    in the next status word: every rank comes back with an error, at every step where a rank can fail"""
+    import vfind_amd
+    from vfind_amd import Engine, LocalGroup
+    world = 3
+    parts = [synth.make_reads(800 + r, 2000, AD20, L=150, n_variants=300) for r in range(world)]
+    for step in (1, 2, 3):
+        engines = [Engine(AD20, table_slots=1 << 14, arena_bytes=1 << 22) for _ in range(world)]
+        try:
+            for e, p in zip(engines, parts):
+                e.submit(p)
+            monkeypatch.setenv("VFIND_TEST_FAIL_ALLREDUCE", f"1:{step}")
+            g = LocalGroup(world)
+            errs = g.reduce(engines, root=0)
+            monkeypatch.delenv("VFIND_TEST_FAIL_ALLREDUCE")
+            assert all(e is not None for e in errs), (step, errs)
+            assert isinstance(errs[1], MemoryError) and "injected" in str(errs[1])
+            assert "rank 1 failed" in str(errs[0]) and "rank 1 failed" in str(errs[2])
+            g.close()
+        finally:
+            for e in engines:
+                e.close()
+
+
 def test_rccl_entry_points_single_rank():
     """vf_comm_unique_id / vf_comm_init / vf_table_allreduce through the C ABI with a communicator of one rank (RCCL refuses
     two ranks on one GPU, so more cannot run on this box): the library loads librccl, creates and destroys a communicator,

@@ -16,7 +16,7 @@ import numpy as np
 from . import _lib
 from ._lib import VfindError, VfParams, VfStats, check
 
-__all__ = ["find_variants", "Engine", "VfindError", "build"]
+__all__ = ["find_variants", "Engine", "LocalGroup", "VfindError", "build"]
 __version__ = "0.1.0"
 
 build = _lib.build
@@ -256,8 +256,14 @@ class Engine:
         check(self._L.vf_comm_init(self._ctx, int(rank), int(world), unique_id))
 
     def allreduce_rccl(self, root: int = 0):
-        """owner-partitioned reduce of all ranks' tables over RCCL, inside the library (vf_table_allreduce)"""
+        """owner-partitioned reduce of all ranks' tables inside the library (vf_table_allreduce): over RCCL after comm_init,
+        between the contexts of a LocalGroup after comm_init_local"""
         check(self._L.vf_table_allreduce(self._ctx, int(root)))
+
+    def comm_init_local(self, rank: int, group: "LocalGroup"):
+        """joins an in-process group (vf_comm_init_local): the exchange then runs between contexts of this process"""
+        check(self._L.vf_comm_init_local(self._ctx, int(rank), group.handle))
+        self._local_group = group                      # keeps the rendezvous alive as long as the context may use it
 
     def allreduce_table(self, group=None, dst: int = 0, transport: str = "auto"):
         """Sum the (key,count) tables of all ranks of a torch.distributed group at rank `dst`.
@@ -337,6 +343,44 @@ class Engine:
 
     def reset_stats(self):
         check(self._L.vf_stats_reset(self._ctx))
+
+
+class LocalGroup:
+    """rendezvous of `world` contexts of one process (vf_comm_local_create): every context joins with comm_init_local and
+    calls allreduce_rccl from a thread of its own (`reduce` does that for a list of engines)"""
+
+    def __init__(self, world: int):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        check(self._L.vf_comm_local_create(int(world), C.byref(h)))
+        self.handle, self.world = h, int(world)
+
+    def close(self):
+        if self.handle:
+            self._L.vf_comm_local_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+    def reduce(self, engines, root: int = 0):
+        """vf_table_allreduce on every engine at once, one thread each; returns the per-rank exceptions (None = fine)"""
+        import threading
+        assert len(engines) == self.world
+        errs = [None] * self.world
+
+        def run(r):
+            try:
+                engines[r].comm_init_local(r, self)
+                engines[r].allreduce_rccl(root)
+            except Exception as e:                      # noqa: BLE001 - handed to the caller, rank by rank
+                errs[r] = e
+        th = [threading.Thread(target=run, args=(r,)) for r in range(self.world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return errs
 
 
 def _to_frame(keys: np.ndarray, offs: np.ndarray, cnts: np.ndarray):

@@ -72,6 +72,9 @@ SYMBOLS = [
     ("vf_comm_unique_id", C.c_int, [_P]),
     ("vf_comm_init", C.c_int, [_P, C.c_int, C.c_int, _P]),
     ("vf_table_allreduce", C.c_int, [_P, C.c_int]),
+    ("vf_comm_local_create", C.c_int, [C.c_int, C.POINTER(_P)]),
+    ("vf_comm_local_destroy", None, [_P]),
+    ("vf_comm_init_local", C.c_int, [_P, C.c_int, _P]),
     ("vf_stats_get", C.c_int, [_P, C.POINTER(VfStats)]),
     ("vf_stats_reset", C.c_int, [_P]),
     ("vf_set_profiling", C.c_int, [_P, C.c_int]),

@@ -65,6 +65,8 @@ static inline uint32_t base_code(unsigned char ch) { return ch == 'A' ? 0u : ch 
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
+struct vf_local_group;
+
 namespace {
 
 struct EventPair { hipEvent_t a, b; int kind; };
@@ -254,6 +256,7 @@ struct vf_ctx {
     uint64_t part[2 * 64] = {};         // entries, key dwords per owner of the latest partition_counts
     uint32_t part_world = 0;            // 0 = stale (the table changed since)
     void *comm = nullptr;               // ncclComm_t of vf_comm_init
+    vf_local_group *local_group = nullptr;   // or the in-process group of vf_comm_init_local (not owned)
     int comm_rank = 0, comm_world = 1;
     // stats / profiling
     std::atomic<uint64_t> n_reads{0}, n_generic{0};
@@ -1367,8 +1370,120 @@ Rccl *rccl() {
             return fail(VF_EDEVICE, std::string(#expr) + ": " + (R->GetErrorString ? R->GetErrorString(_r) : "RCCL error")); \
     } while (0)
 
+// ---- transports of the exchange ---------------------------------------------------------------------------------------
+// vf_table_allreduce is written against these five calls.  RcclTransport is the product path (one process per GPU, xGMI);
+// LocalTransport connects contexts of ONE process - a host that drives several GPUs from one process, and the tests, where
+// RCCL refuses two ranks on one device: every byte moves by a device-to-device copy behind a host rendezvous, so the same
+// bucket / offset / merge code runs with G > 1 on a one-GPU box.
+namespace {
+struct Transport {
+    virtual ~Transport() {}
+    // count 64-bit words from every rank, rank r's at recv + r * count (device pointers; in stream order)
+    virtual int all_gather(const uint64_t *send, uint64_t *recv, size_t count, hipStream_t st) = 0;
+    // one round of point-to-point transfers: the calls between begin and end are matched with the peers' and complete
+    // (in stream order) behind end.  Every rank of the communicator enters every round, with or without transfers.
+    virtual int begin() = 0;
+    virtual int send(const void *p, size_t bytes, int peer, hipStream_t st) = 0;
+    virtual int recv(void *p, size_t bytes, int peer, hipStream_t st) = 0;
+    virtual int end(hipStream_t st) = 0;
+};
+
+struct RcclTransport : Transport {
+    Rccl *R; ncclComm_t comm;
+    RcclTransport(Rccl *r, ncclComm_t c) : R(r), comm(c) {}
+    int all_gather(const uint64_t *send, uint64_t *recv, size_t count, hipStream_t st) override { NCCL_TRY(R->AllGather(send, recv, count, ncclUint64, comm, st)); return VF_OK; }
+    int begin() override { NCCL_TRY(R->GroupStart()); return VF_OK; }
+    int send(const void *p, size_t bytes, int peer, hipStream_t st) override { NCCL_TRY(R->Send(p, bytes, ncclUint8, peer, comm, st)); return VF_OK; }
+    int recv(void *p, size_t bytes, int peer, hipStream_t st) override { NCCL_TRY(R->Recv(p, bytes, ncclUint8, peer, comm, st)); return VF_OK; }
+    int end(hipStream_t) override { NCCL_TRY(R->GroupEnd()); return VF_OK; }
+};
+}  // namespace
+
+// The rendezvous of a LocalTransport group: one per group of contexts, shared by their threads.
+struct vf_local_group {
+    int world = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    bool broken = false;                                     // a rank left with an error: nobody waits any more
+    struct Post { const void *p = nullptr; size_t bytes = 0; int dev = 0; };
+    std::vector<Post> gather;                                // [rank]
+    std::vector<Post> mail;                                  // [from * world + to]
+    // every rank arrives; false = the group is broken (a rank failed or left)
+    bool barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        if (broken) return false;
+        const uint64_t gen = generation;
+        if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); return true; }
+        cv.wait(lk, [&] { return generation != gen || broken; });
+        return !broken;
+    }
+    void abort() { { std::lock_guard<std::mutex> g(mu); broken = true; } cv.notify_all(); }
+};
+
+namespace {
+struct LocalTransport : Transport {
+    vf_local_group *g; int me, dev;
+    struct Op { bool is_send; void *p; size_t bytes; int peer; };
+    std::vector<Op> ops;
+    LocalTransport(vf_local_group *g_, int rank, int dev_) : g(g_), me(rank), dev(dev_) {}
+    int broken() { return fail(VF_EDEVICE, "local exchange: a peer left the exchange with an error"); }
+    int copy(void *dst, const vf_local_group::Post &src, size_t bytes, hipStream_t st) {
+        if (src.dev == dev) HIP_TRY(hipMemcpyAsync(dst, src.p, bytes, hipMemcpyDeviceToDevice, st));
+        else HIP_TRY(hipMemcpyPeerAsync(dst, dev, src.p, src.dev, bytes, st));
+        return VF_OK;
+    }
+    int all_gather(const uint64_t *send, uint64_t *recv, size_t count, hipStream_t st) override {
+        HIP_TRY(hipStreamSynchronize(st));                   // what `send` holds was written in stream order
+        { std::lock_guard<std::mutex> lk(g->mu); g->gather[me] = {send, count * sizeof(uint64_t), dev}; }
+        if (!g->barrier()) return broken();
+        int rc = VF_OK;
+        for (int r = 0; r < g->world && !rc; ++r) {
+            vf_local_group::Post src;
+            { std::lock_guard<std::mutex> lk(g->mu); src = g->gather[r]; }
+            if (src.bytes != count * sizeof(uint64_t)) rc = fail(VF_EDEVICE, "local exchange: all_gather counts differ between ranks");
+            else rc = copy(recv + (size_t)r * count, src, src.bytes, st);
+        }
+        if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(VF_EDEVICE, "hipStreamSynchronize failed");
+        if (rc) { g->abort(); return rc; }
+        if (!g->barrier()) return broken();                  // nobody reuses its send buffer before everyone has copied
+        return VF_OK;
+    }
+    int begin() override { ops.clear(); return VF_OK; }
+    int send(const void *p, size_t bytes, int peer, hipStream_t) override { ops.push_back({true, const_cast<void *>(p), bytes, peer}); return VF_OK; }
+    int recv(void *p, size_t bytes, int peer, hipStream_t) override { ops.push_back({false, p, bytes, peer}); return VF_OK; }
+    int end(hipStream_t st) override {
+        HIP_TRY(hipStreamSynchronize(st));
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            for (const Op &o : ops) if (o.is_send) g->mail[(size_t)me * g->world + o.peer] = {o.p, o.bytes, dev};
+        }
+        if (!g->barrier()) return broken();
+        int rc = VF_OK;
+        for (const Op &o : ops) {
+            if (o.is_send || rc) continue;
+            vf_local_group::Post src;
+            { std::lock_guard<std::mutex> lk(g->mu); src = g->mail[(size_t)o.peer * g->world + me]; }
+            if (!src.p || src.bytes != o.bytes) rc = fail(VF_EDEVICE, "local exchange: a receive has no matching send of the same size");
+            else rc = copy(o.p, src, o.bytes, st);
+        }
+        if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(VF_EDEVICE, "hipStreamSynchronize failed");
+        if (rc) { g->abort(); return rc; }
+        if (!g->barrier()) return broken();
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            for (const Op &o : ops) if (o.is_send) g->mail[(size_t)me * g->world + o.peer] = {};
+        }
+        ops.clear();
+        return VF_OK;
+    }
+};
+}  // namespace
+
 static void vf_comm_release(vf_ctx *c) {
     if (c->comm) { if (Rccl *R = rccl()) (void)R->CommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
+    c->local_group = nullptr;
     c->comm_rank = 0; c->comm_world = 1;
 }
 
@@ -1402,86 +1517,179 @@ static int vf_comm_init_impl(vf_ctx *c, int rank, int world, const void *id128) 
     return VF_OK;
 }
 
-// Owner-partitioned reduce of the count tables of all ranks (primary design):
-//   1. every rank buckets its entries by owner (hash tag -> one of `world`), sizes go round by ncclAllGather;
-//   2. ONE grouped ncclSend / ncclRecv exchange: bucket o of every rank to rank o (each entry crosses xGMI once, all
-//      links of a GPU busy at once, no ring);
-//   3. every owner empties its table and merges its own bucket and the world - 1 it received: its share, fully summed;
-//   4. the shares -- disjoint key sets -- go to `root` (sizes by ncclAllGather, one grouped exchange), which merges them.
-// Afterwards root's table is the sum of all tables; every other rank is left holding its own share.
+static int vf_comm_local_create_impl(int world, vf_local_group **out);
+extern "C" int vf_comm_local_create(int world, vf_local_group **out) { return vf_guard([&] { return vf_comm_local_create_impl(world, out); }); }
+static int vf_comm_local_create_impl(int world, vf_local_group **out) {
+    if (!out) return fail(VF_EINVAL, "null argument");
+    *out = nullptr;
+    if (world < 1 || world > 64) return fail(VF_EINVAL, "world out of range (1..64 contexts)");
+    std::unique_ptr<vf_local_group> g(new vf_local_group);
+    g->world = world;
+    g->gather.resize((size_t)world);
+    g->mail.resize((size_t)world * (size_t)world);
+    *out = g.release();
+    return VF_OK;
+}
+extern "C" void vf_comm_local_destroy(vf_local_group *g) { delete g; }
+
+static int vf_comm_init_local_impl(vf_ctx *c, int rank, vf_local_group *g);
+extern "C" int vf_comm_init_local(vf_ctx *c, int rank, vf_local_group *g) { return vf_guard([&] { return vf_comm_init_local_impl(c, rank, g); }); }
+static int vf_comm_init_local_impl(vf_ctx *c, int rank, vf_local_group *g) {
+    if (!c || !g) return fail(VF_EINVAL, "null argument");
+    if (rank < 0 || rank >= g->world) return fail(VF_EINVAL, "rank out of range for this group");
+    vf_comm_release(c);
+    c->local_group = g; c->comm_rank = rank; c->comm_world = g->world;
+    return VF_OK;
+}
+
+// test hook: VFIND_TEST_FAIL_ALLREDUCE=<rank>:<step> makes that rank fail at local step 1 (buckets), 2 (buffers) or 3 (share)
+static bool allreduce_test_fail(int rank, int step) {
+    const char *e = getenv("VFIND_TEST_FAIL_ALLREDUCE");
+    int r = -1, s = -1;
+    return e && sscanf(e, "%d:%d", &r, &s) == 2 && r == rank && s == step;
+}
+
+// Owner-partitioned reduce of the count tables of all ranks (primary design; the multi-GPU form of the serial
+// reduce of lib.rs:292-306):
+//   1. every rank buckets its entries by owner (hash tag -> one of `world`); sizes and a status word go round (all-gather 1);
+//   2. every rank sizes and allocates ALL its buffers from those sizes - receive side of the bucket exchange, its share,
+//      root's receive side of the share gather (upper bounds: merged blobs only shrink) - and the statuses go round again
+//      (all-gather 2), so that nobody enters the exchange unless everybody can;
+//   3. ONE round of sends / receives: bucket o of every rank to rank o (each entry crosses xGMI once, all links of a GPU
+//      busy at once, no ring);
+//   4. every owner empties its table, merges its own bucket and the world - 1 it received - its share, fully summed - and
+//      exports it; share sizes and statuses go round (all-gather 3);
+//   5. the shares - disjoint key sets - go to `root` in one round, which merges them.
+// A rank that fails locally (no memory for a buffer, a table that cannot grow) says so in the next status word and every
+// rank leaves with an error together: nobody is left waiting in a receive for a peer that has gone (round 2 returned early
+// between the collectives).  Afterwards root's table is the sum of all tables; every other rank holds its own share.
+static int allreduce_over(vf_ctx *c, Transport &T, int root) {
+    const int G = c->comm_world, me = c->comm_rank;
+    hipStream_t st = c->main_stream;
+    DevBuf<uint8_t> sendbuf, recvbuf, sharebuf, gatherbuf;
+    DevBuf<uint64_t> d_words;
+    struct Free { DevBuf<uint8_t> &a, &b, &c2, &d; DevBuf<uint64_t> &e; ~Free() { a.release(); b.release(); c2.release(); d.release(); e.release(); } } fr{sendbuf, recvbuf, sharebuf, gatherbuf, d_words};
+    const size_t W1 = (size_t)G + 1;                                   // words a rank contributes to all-gather 1: G sizes + status
+    int rc = d_words.ensure(W1 + W1 * (size_t)G + 2 * ((size_t)G + 1));
+    // statuses of all ranks after a gather of `words` words per rank whose last word is the status; VF_OK only if all are
+    auto agreed = [&](const std::vector<uint64_t> &all, size_t words, int mine) -> int {
+        if (mine) return mine;                                         // (own message already set)
+        for (int r = 0; r < G; ++r)
+            if (all[(size_t)r * words + words - 1] != 0)
+                return fail((int)all[(size_t)r * words + words - 1], "table exchange: rank " + std::to_string(r) + " failed (" + std::to_string(all[(size_t)r * words + words - 1]) + "), every rank leaves");
+        return VF_OK;
+    };
+    auto gather_words = [&](const std::vector<uint64_t> &mine_w, std::vector<uint64_t> &all_w) -> int {
+        const size_t words = mine_w.size();
+        all_w.assign(words * (size_t)G, 0);
+        if (!d_words.p) return fail(VF_ENOMEM, "hipMalloc failed");    // (without the staging words there is no way to tell the peers)
+        HIP_TRY(hipMemcpyAsync(d_words.p, mine_w.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        int r2 = T.all_gather(d_words.p, d_words.p + words, words, st);
+        if (r2) return r2;
+        HIP_TRY(hipMemcpyAsync(all_w.data(), d_words.p + words, words * (size_t)G * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return VF_OK;
+    };
+    if (rc) return rc;                                                 // (nothing collective has started: the peers time out in their own way)
+
+    // 1. buckets
+    std::vector<uint64_t> mine(G, 0), soff(G + 1, 0);
+    if (!rc && allreduce_test_fail(me, 1)) rc = fail(VF_ENOMEM, "injected failure (VFIND_TEST_FAIL_ALLREDUCE)");
+    if (!rc) rc = vf_table_partition_sizes(c, (uint32_t)G, mine.data());
+    for (int o = 0; o < G; ++o) soff[o + 1] = soff[o] + ((mine[o] + 255) & ~255ull);
+    if (!rc) rc = sendbuf.ensure(soff[G] + 256);
+    for (int o = 0; o < G && !rc; ++o) rc = vf_table_partition_export(c, (uint32_t)G, (uint32_t)o, sendbuf.p + soff[o], mine[o], nullptr);
+    std::vector<uint64_t> w1(mine), all1;
+    w1.push_back((uint64_t)rc);
+    int grc = gather_words(w1, all1);
+    if (grc) return grc;
+    if ((rc = agreed(all1, W1, rc))) return rc;
+    auto bucket = [&](int from, int owner) { return all1[(size_t)from * W1 + owner]; };
+
+    // 2. every buffer this rank will need, from upper bounds
+    std::vector<uint64_t> roff(G + 1, 0);
+    for (int q = 0; q < G; ++q) roff[q + 1] = roff[q] + ((bucket(q, me) + 255) & ~255ull);
+    uint64_t share_cap = 0;                                            // my share: the sum of what it is merged from
+    for (int q = 0; q < G; ++q) share_cap += bucket(q, me);
+    std::vector<uint64_t> gcap(G + 1, 0);                              // root: room for every other rank's share
+    if (me == root)
+        for (int q = 0; q < G; ++q) {
+            uint64_t cap_q = 0;
+            for (int p = 0; p < G; ++p) cap_q += bucket(p, q);
+            gcap[q + 1] = gcap[q] + (q == me ? 0 : ((cap_q + 255) & ~255ull));
+        }
+    if (allreduce_test_fail(me, 2)) rc = fail(VF_ENOMEM, "injected failure (VFIND_TEST_FAIL_ALLREDUCE)");
+    if (!rc) rc = recvbuf.ensure(roff[G] + 256);
+    if (!rc && me != root) rc = sharebuf.ensure(share_cap + 256);
+    if (!rc && me == root) rc = gatherbuf.ensure(gcap[G] + 256);
+    std::vector<uint64_t> w2{(uint64_t)rc}, all2;
+    if ((grc = gather_words(w2, all2))) return grc;
+    if ((rc = agreed(all2, 1, rc))) return rc;
+
+    // 3. bucket `me` of every rank comes here
+    if ((rc = T.begin())) return rc;
+    for (int p = 0; p < G && !rc; ++p) {
+        if (p == me) continue;
+        rc = T.send(sendbuf.p + soff[p], mine[p], p, st);
+        if (!rc) rc = T.recv(recvbuf.p + roff[p], bucket(p, me), p, st);
+    }
+    if (!rc) rc = T.end(st);
+    if (rc) return rc;                                                 // (the transport itself failed: nothing to agree over)
+    HIP_TRY(hipStreamSynchronize(st));
+
+    // 4. this rank's share
+    if (allreduce_test_fail(me, 3)) rc = fail(VF_ENOMEM, "injected failure (VFIND_TEST_FAIL_ALLREDUCE)");
+    if (!rc) rc = vf_table_clear(c);
+    if (!rc) rc = vf_table_merge(c, sendbuf.p + soff[me], mine[me]);
+    for (int q = 0; q < G && !rc; ++q)
+        if (q != me) rc = vf_table_merge(c, recvbuf.p + roff[q], bucket(q, me));
+    uint64_t share = 0;
+    if (!rc) rc = vf_table_export_size(c, &share);
+    if (!rc && me != root) {
+        if (share > share_cap) rc = fail(VF_EDEVICE, "table exchange: a merged share is larger than its parts (internal error)");
+        else rc = vf_table_export(c, sharebuf.p, share, nullptr);
+    }
+    std::vector<uint64_t> w3{share, (uint64_t)rc}, all3;
+    if ((grc = gather_words(w3, all3))) return grc;
+    if ((rc = agreed(all3, 2, rc))) return rc;
+
+    // 5. shares to root
+    if ((rc = T.begin())) return rc;
+    if (me != root) rc = T.send(sharebuf.p, share, root, st);
+    else
+        for (int q = 0; q < G && !rc; ++q) {
+            if (q == me) continue;
+            if (all3[(size_t)q * 2] > gcap[q + 1] - gcap[q]) rc = fail(VF_EDEVICE, "table exchange: a share is larger than its parts (internal error)");
+            else rc = T.recv(gatherbuf.p + gcap[q], all3[(size_t)q * 2], q, st);
+        }
+    if (!rc) rc = T.end(st);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    if (me == root)
+        for (int q = 0; q < G; ++q)
+            if (q != me && (rc = vf_table_merge(c, gatherbuf.p + gcap[q], all3[(size_t)q * 2]))) return rc;
+    return VF_OK;
+}
+
 static int vf_table_allreduce_impl(vf_ctx *c, int root);
 extern "C" int vf_table_allreduce(vf_ctx *c, int root) { return vf_guard([&] { return vf_table_allreduce_impl(c, root); }); }
 static int vf_table_allreduce_impl(vf_ctx *c, int root) {
     if (!c) return fail(VF_EINVAL, "null context");
-    const int G = c->comm_world, me = c->comm_rank;
+    const int G = c->comm_world;
     if (G == 1) return VF_OK;
-    if (!c->comm) return fail(VF_EINVAL, "vf_comm_init has not been called");
+    if (!c->comm && !c->local_group) return fail(VF_EINVAL, "vf_comm_init has not been called");
     if (root < 0 || root >= G) return fail(VF_EINVAL, "root out of range");
+    HIP_TRY(hipSetDevice(c->dev));
+    if (c->local_group) {
+        LocalTransport T(c->local_group, c->comm_rank, c->dev);
+        const int rc = allreduce_over(c, T, root);
+        if (rc) { const std::string keep = g_err; c->local_group->abort(); g_err = keep; }      // peers waiting at the rendezvous leave too
+        return rc;
+    }
     Rccl *R = rccl();
     if (!R) return fail(VF_EDEVICE, "librccl.so.1 is not loadable");
-    ncclComm_t comm = (ncclComm_t)c->comm;
-    HIP_TRY(hipSetDevice(c->dev));
-    hipStream_t st = c->main_stream;
-    int rc;
-    // 1. buckets
-    std::vector<uint64_t> mine(G), all((size_t)G * G);
-    if ((rc = vf_table_partition_sizes(c, (uint32_t)G, mine.data()))) return rc;
-    std::vector<uint64_t> soff(G + 1, 0);
-    for (int o = 0; o < G; ++o) soff[o + 1] = soff[o] + ((mine[o] + 255) & ~255ull);
-    DevBuf<uint8_t> sendbuf, recvbuf;
-    DevBuf<uint64_t> d_sizes;
-    struct Free { DevBuf<uint8_t> &a, &b; DevBuf<uint64_t> &c; ~Free() { a.release(); b.release(); c.release(); } } fr{sendbuf, recvbuf, d_sizes};
-    if ((rc = sendbuf.ensure(soff[G] + 256))) return rc;
-    for (int o = 0; o < G; ++o)
-        if ((rc = vf_table_partition_export(c, (uint32_t)G, (uint32_t)o, sendbuf.p + soff[o], mine[o], nullptr))) return rc;
-    if ((rc = d_sizes.ensure((size_t)G + (size_t)G * G))) return rc;
-    HIP_TRY(hipMemcpyAsync(d_sizes.p, mine.data(), G * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    NCCL_TRY(R->AllGather(d_sizes.p, d_sizes.p + G, G, ncclUint64, comm, st));
-    HIP_TRY(hipMemcpyAsync(all.data(), d_sizes.p + G, (size_t)G * G * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    // 2. bucket `me` of every rank comes here
-    std::vector<uint64_t> roff(G + 1, 0);
-    for (int q = 0; q < G; ++q) roff[q + 1] = roff[q] + ((all[(size_t)q * G + me] + 255) & ~255ull);
-    if ((rc = recvbuf.ensure(roff[G] + 256))) return rc;
-    NCCL_TRY(R->GroupStart());
-    for (int p = 0; p < G; ++p) {
-        if (p == me) continue;
-        NCCL_TRY(R->Send(sendbuf.p + soff[p], mine[p], ncclUint8, p, comm, st));
-        NCCL_TRY(R->Recv(recvbuf.p + roff[p], all[(size_t)p * G + me], ncclUint8, p, comm, st));
-    }
-    NCCL_TRY(R->GroupEnd());
-    HIP_TRY(hipStreamSynchronize(st));
-    // 3. this rank's share
-    if ((rc = vf_table_clear(c))) return rc;
-    if ((rc = vf_table_merge(c, sendbuf.p + soff[me], mine[me]))) return rc;
-    for (int q = 0; q < G; ++q)
-        if (q != me && (rc = vf_table_merge(c, recvbuf.p + roff[q], all[(size_t)q * G + me]))) return rc;
-    // 4. shares to root
-    uint64_t share = 0;
-    if ((rc = vf_table_export_size(c, &share))) return rc;
-    std::vector<uint64_t> shares(G);
-    HIP_TRY(hipMemcpyAsync(d_sizes.p, &share, sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    NCCL_TRY(R->AllGather(d_sizes.p, d_sizes.p + 1, 1, ncclUint64, comm, st));
-    HIP_TRY(hipMemcpyAsync(shares.data(), d_sizes.p + 1, G * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (me != root) {
-        if ((rc = sendbuf.ensure(share + 256))) return rc;
-        if ((rc = vf_table_export(c, sendbuf.p, share, nullptr))) return rc;
-        NCCL_TRY(R->Send(sendbuf.p, share, ncclUint8, root, comm, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        return VF_OK;
-    }
-    std::vector<uint64_t> goff(G + 1, 0);
-    for (int q = 0; q < G; ++q) goff[q + 1] = goff[q] + (q == me ? 0 : ((shares[q] + 255) & ~255ull));
-    if ((rc = recvbuf.ensure(goff[G] + 256))) return rc;
-    NCCL_TRY(R->GroupStart());
-    for (int q = 0; q < G; ++q)
-        if (q != me) NCCL_TRY(R->Recv(recvbuf.p + goff[q], shares[q], ncclUint8, q, comm, st));
-    NCCL_TRY(R->GroupEnd());
-    HIP_TRY(hipStreamSynchronize(st));
-    for (int q = 0; q < G; ++q)
-        if (q != me && (rc = vf_table_merge(c, recvbuf.p + goff[q], shares[q]))) return rc;
-    return VF_OK;
+    RcclTransport T(R, (ncclComm_t)c->comm);
+    return allreduce_over(c, T, root);
 }
 
 static int vf_finish_impl(vf_ctx *c, vf_result **out);
