@@ -52,6 +52,61 @@ def tie_sensitive_fraction(data, offs, ads, oracle, budget_s=8.0, max_reads=400)
                     "kernel == oracle there under tie policy P, oracle == parasail is unpinned"}
 
 
+def other_config_leg(vfind_amd, synth, oracle, name, device, host_threads, n, L, adapter_len, variants, sub_rate, indel_rate, seed,
+                     steps=10, warmup=2):
+    """one of BASELINE.json's other shapes on this GPU, resident in HBM like the headline: its own ms_per_step and path roofline,
+    and the table left by the last step compared - whole - with the CPU oracle's over the same reads"""
+    import numpy as np
+    import torch
+    ads = synth.adapters(seed, adapter_len)
+    gen = synth.Generator(seed, ads, read_len=L, n_variants=variants, sub_rate=sub_rate, indel_rate=indel_rate)
+    rows_h, lens_h = gen.packed(0, n, host_threads)
+    dev = torch.device("cuda", device)
+    rows = torch.from_numpy(rows_h).to(dev)
+    lens = torch.from_numpy(lens_h.view(np.int16)).to(dev)
+    del rows_h, lens_h
+    torch.cuda.synchronize(dev)
+    slots = 1 << 16
+    while slots < max(2 * min(variants, n), n // 8):
+        slots <<= 1
+    eng = vfind_amd.Engine(ads, device=device, table_slots=slots, arena_bytes=1 << 30)
+    try:
+        def step():
+            eng.clear()
+            eng.process_device(rows.data_ptr(), gen.row_dwords, lens.data_ptr(), n)
+        for _ in range(warmup):
+            step()
+        eng.sync()
+        eng.reset_stats()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        eng.sync()
+        dt = time.perf_counter() - t0
+        st = eng.stats()
+        got = eng.finish_dict()
+        data, offs = gen.ascii(0, n, host_threads)
+        tq = time.perf_counter()
+        want = oracle.count((data, offs), ads, n_threads=host_threads)
+        cpu_dt = time.perf_counter() - tq
+        if got != want:
+            raise SystemExit(f"PARITY FAILED ({name}): device table differs from the CPU oracle")
+        ms = dt / steps * 1e3
+        gbps = n * b_alg(L) / (ms * 1e-3) / 1e9
+        return {"workload": f"{n} synthetic {L} bp reads resident in HBM, {adapter_len} bp adapters, {variants} variants, "
+                            f"substitutions {sub_rate}, indels {indel_rate}, default alignment params",
+                "value": round(n * steps / dt / 1e6, 2), "unit": "M reads/s", "ms_per_step": round(ms, 4), "steps": steps,
+                "roofline_path": {"bound": "hbm", "achieved": round(gbps, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": round(gbps / HBM_PEAK_GBPS, 6), "alg_bytes_per_read": b_alg(L)},
+                "alignments_per_read": round((st["dp_prefix"] + st["dp_suffix"]) / steps / n, 3),
+                "parity_full_table": True, "table_rows": len(got),
+                "cpu_oracle_M_reads_per_s": round(n / cpu_dt / 1e6, 3), "cpu_threads": host_threads}
+    finally:
+        eng.close()
+        del rows, lens
+
+
 def pcie_inclusive_leg(vfind_amd, gen, ads, n, L, device, slots, host_threads, rounds=3, queue_len=8):
     """reads/s with the batches in page-locked HOST memory when the clock starts: vf_batch_acquire / vf_batch_submit, queue_len
     slots, hipMemcpyAsync of batch k + 1 overlapped with the kernels of batch k.  The staging is filled once (the host decoder's
@@ -135,6 +190,7 @@ def main():
     ap.add_argument("--table-slots", type=int, default=0, help="count-table slots (0 = 2x the variant library, power of two)")
     ap.add_argument("--no-extras", action="store_true", help="skip the legs beside the headline: result build, PCIe-inclusive, end-to-end FASTQ, tie-sensitive fraction")
     ap.add_argument("--e2e-reads", type=int, default=2_000_000, help="reads of the gzip FASTQ file of the end-to-end leg")
+    ap.add_argument("--other-config-reads", type=int, default=2_000_000, help="resident reads of each of the other BASELINE shapes (extras)")
     ap.add_argument("--merge-transport", default="auto", choices=["auto", "rccl", "torch"],
                     help="final table reduce: rccl = the library's own exchange (vf_comm_init / vf_table_allreduce), torch = the same "
                          "algorithm with torch.distributed moving the bytes; auto = rccl when the backend is nccl")
@@ -270,6 +326,20 @@ def main():
             tq = time.perf_counter()
             oracle.count((sb[: s3 * L], so[: s3 + 1]), ads, n_threads=3)
             cpu["at_reference_default_threads"] = {"value": round(s3 / max(time.perf_counter() - tq, 1e-4) / 1e6, 4), "cores": 3, "sample_reads": s3}
+            # BASELINE.md 3's shape: the reference's own threading (seq_io::parallel_fastq, lib.rs:271-306) - W workers run the
+            # `work` closure on record sets, ONE thread reduces every record in input order; best of 3, at the reference's
+            # default W = 3 and at every core of this job's share
+            ref_shape = {}
+            for w in (3, cores):
+                best_w = None
+                for _ in range(3):
+                    tq = time.perf_counter()
+                    oracle.count_reference_shape((sb[: s3 * L], so[: s3 + 1]), ads, n_workers=w)
+                    dtw = time.perf_counter() - tq
+                    best_w = dtw if best_w is None else min(best_w, dtw)
+                ref_shape[f"workers_{w}"] = {"value": round(s3 / max(best_w, 1e-4) / 1e6, 4), "unit": "M reads/s", "workers": w, "reducers": 1}
+            cpu["reference_shape"] = dict(ref_shape, sample_reads=s3, runs="best of 3",
+                                          what="W worker threads -> one serial reducer on the calling thread (lib.rs:271-306)")
             del sb, so
         # fraction of this input's accepted alignments whose `length` depends on the aligner's tie-breaking (BASELINE.md 4,
         # SURVEY App. B.4): sampled with the exhaustive co-optimal enumerator of oracle/pyref.py on reads of the probe
@@ -306,6 +376,22 @@ def main():
     eng.set_profiling(False)
     st = eng.stats()
     st_k, k_steps = st, max(args.steps, 1)
+    # the same window four more times (N = 1; `value`, `ms_per_step` and `steps` stay those of the FIRST window): boxes of the
+    # pool differ by up to 10 %, and one 20-step window is a thin basis for a 3 % conclusion
+    spread = None
+    if world == 1 and not args.no_extras:
+        wins = [elapsed / args.steps * 1e3]
+        for _ in range(4):
+            torch.cuda.synchronize(dev)
+            tw = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            eng.sync()
+            wins.append((time.perf_counter() - tw) / args.steps * 1e3)
+        sw = sorted(wins)
+        spread = {"windows": len(wins), "steps_per_window": args.steps, "ms_per_step": [round(x, 4) for x in wins],
+                  "min": round(sw[0], 4), "median": round(sw[len(sw) // 2], 4), "max": round(sw[-1], 4),
+                  "M_reads_per_s_median": round(n / (sw[len(sw) // 2] * 1e-3) / 1e6, 1)}
 
     # ---- full-size parity: the table left by the last timed step (resident packed path, all n reads)
     # against the oracle's table of the same reads, when the CPU baseline sample covered them all
@@ -327,6 +413,16 @@ def main():
         del keys, offs, cnts
         extras["pcie_inclusive"] = pcie_inclusive_leg(vfind_amd, gen, ads, n, L, local_rank, slots, host_threads)
         extras["end_to_end"] = end_to_end_leg(vfind_amd, gen, ads, args.e2e_reads, local_rank, slots)
+        if not args.no_parity and not args.no_cpu_baseline:
+            # BASELINE.json configs[3] and configs[4] in shape (their read counts are 8-GPU jobs), each with its whole table checked
+            from oracle import oracle as _oracle
+            oc_n = args.other_config_reads
+            extras["other_configs"] = {
+                "cfg4_shape_dp_on_every_read": other_config_leg(vfind_amd, synth, _oracle, "cfg 4 shape", local_rank, host_threads, oc_n, 150, 20,
+                                                                1_000_000, 0.15, 0.0, 0x5EED0004),
+                "cfg5_shape_300bp_30bp_adapters": other_config_leg(vfind_amd, synth, _oracle, "cfg 5 shape", local_rank, host_threads, oc_n, 300, 30,
+                                                                   10_000_000, 0.005, 0.0005, 0x5EED0005),
+            }
 
     # per-kernel durations of every kernel kind: the same steps again with all brackets on (not in `value`)
     if ev_mode == 2:
@@ -446,6 +542,7 @@ def main():
             "parity_gate": parity, "parity_full_size": parity_full, "table_cleared_each_step": not keep_table,
             "merge_ms": None if merge_ms is None else round(merge_ms, 3), "merge_error": merge_error,
             "merge_transport": None if world == 1 else {"rccl": "rccl (vf_table_allreduce)"}.get(getattr(eng, "last_merge_transport", args.merge_transport), getattr(eng, "last_merge_transport", args.merge_transport)),
+            "value_spread": spread, "other_configs": extras.get("other_configs"),
             "finish": extras.get("finish"), "pcie_inclusive": extras.get("pcie_inclusive"), "end_to_end": extras.get("end_to_end"),
             "tie_sensitive_frac": tie, "valu_util": valu_util_from_profiles(),
             "per_step": {"dp_prefix_tasks": st["dp_prefix"] // steps, "dp_suffix_tasks": st["dp_suffix"] // steps, "insert_path_reads": st["insert_path"] // steps,

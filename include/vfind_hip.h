@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 2
+#define VF_ABI_VERSION 3
 
 enum {
     VF_OK = 0,
@@ -182,6 +182,12 @@ int vf_table_clear(vf_ctx *ctx);
 int vf_table_export_size(vf_ctx *ctx, uint64_t *nbytes);
 int vf_table_export(vf_ctx *ctx, void *d_dst, uint64_t capacity, uint64_t *written);
 int vf_table_merge(vf_ctx *ctx, const void *d_blob, uint64_t nbytes);   /* makes room first (grows the table / key arena) */
+/* The rule above made enforceable: everything queued so far on `hip_stream` (a hipStream_t of the caller, NULL = the
+ * null stream) becomes a dependency of whatever this context does next with device memory the caller hands it
+ * (vf_table_export, vf_table_merge, vf_finish_blobs, vf_process_device_packed): an event recorded on the caller's stream,
+ * waited for on the library's streams, no host synchronisation.  A fill or a collective still running on a buffer when
+ * it was handed over once cost a two-rank rehearsal its counts (round 2, two_1.log). */
+int vf_wait_stream(vf_ctx *ctx, void *hip_stream);
 
 /* Owner-partitioned exchange: every key has one owner among `world` GPUs (a function of its hash).  partition_sizes gives
  * the byte size of each owner's share of this GPU's table (world values), partition_export writes one share in the format

@@ -56,6 +56,8 @@ def lib():
         L.vfo_spans.argtypes = [C.POINTER(_Params), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
         L.vfo_count.restype = C.c_int
         L.vfo_count.argtypes = [C.POINTER(_Params), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
+        L.vfo_count_reference_shape.restype = C.c_int
+        L.vfo_count_reference_shape.argtypes = [C.POINTER(_Params), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
         L.vfo_count_fastq.restype = C.c_int
         L.vfo_count_fastq.argtypes = [C.POINTER(_Params), C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.vfo_table_free.argtypes = [C.c_void_p]
@@ -162,6 +164,16 @@ def count(reads_or_packed, adapters, n_threads: int = 1, **kw) -> dict:
     P = _params(adapters, **kw)
     tab = C.c_void_p()
     _check(lib().vfo_count(C.byref(P), data.ctypes.data, offs.ctypes.data, len(offs) - 1, n_threads, C.byref(tab)))
+    return _dump(tab)
+
+
+def count_reference_shape(reads_or_packed, adapters, n_workers: int = 3, **kw) -> dict:
+    """the same table in the reference's threading shape (lib.rs:271-306): n_workers run the `work` closure on record sets,
+    the calling thread runs the reduce closure on every record in input order (BASELINE.md 3's CPU baseline)"""
+    data, offs = reads_or_packed if isinstance(reads_or_packed, tuple) else pack_reads(reads_or_packed)
+    P = _params(adapters, **kw)
+    tab = C.c_void_p()
+    _check(lib().vfo_count_reference_shape(C.byref(P), data.ctypes.data, offs.ctypes.data, len(offs) - 1, n_workers, C.byref(tab)))
     return _dump(tab)
 
 

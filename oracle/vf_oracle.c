@@ -15,6 +15,7 @@
  *   vfo_find_adapter_match    find_adapter_match                   src/lib.rs:141-166
  *   vfo_translate             translate + both tables              src/lib.rs:16-44,52-77,86-95
  *   vfo_spans / vfo_count     the work + reduce closures           src/lib.rs:275-306
+ *   vfo_count_reference_shape the same in parallel_fastq's shape   src/lib.rs:271-306 (W workers, one serial reducer)
  *   vfo_count_fastq           File->MultiGzDecoder->Reader chain   src/lib.rs:233-234
  *
  * Pinning: tests/test_oracle_golden.py checks this file against every known-answer vector the
@@ -28,6 +29,7 @@
 #include <limits.h>
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -374,6 +376,75 @@ int vfo_count(const vfo_params *p, const uint8_t *bytes, const uint64_t *offs, i
     int rc = vfo_run(p, bytes, offs, nreads, NULL, NULL, t, nthreads);
     if (rc) { vfo_table_free(t); *out = NULL; return rc; }
     *out = t; return 0;
+}
+
+/* The same table in the reference's own threading shape (lib.rs:271-306, seq_io::parallel_fastq): `nworkers` pool threads
+ * run the `work` closure (:275-291: both adapter searches) on record sets, and ONE thread - the caller - runs the reduce
+ * closure (:292-306: translate, hash insert) on every record, set by set, in input order.  This is what BASELINE.md 3 calls
+ * the CPU baseline's shape; vfo_count above (a table per thread, merged at the end) is kinder to the CPU.  Record sets of
+ * kSet reads; a worker takes the next set that has no owner, the reducer waits for the set it needs. */
+#include <stdatomic.h>
+enum { kSet = 2048 };
+typedef struct {
+    const vfo_params *p; const vfo_derived *d;
+    const uint8_t *bytes; const uint64_t *offs; int64_t nreads, nsets;
+    int64_t *starts, *ends;
+    atomic_llong next_set;
+    atomic_int *done;                                   /* per set */
+} vfo_sets;
+static void *vfo_set_worker(void *arg) {
+    vfo_sets *S = (vfo_sets *)arg;
+    int mmax = S->p->prefix_len > S->p->suffix_len ? S->p->prefix_len : S->p->suffix_len;
+    int *ws = (int *)malloc(sizeof(int) * 5 * (size_t)(mmax + 1));
+    for (;;) {
+        const int64_t s = atomic_fetch_add(&S->next_set, 1);
+        if (s >= S->nsets) break;
+        const int64_t lo = s * kSet, hi = lo + kSet < S->nreads ? lo + kSet : S->nreads;
+        for (int64_t r = lo; r < hi; ++r)
+            vfo_read_span(S->p, S->d, S->bytes + S->offs[r], (int64_t)(S->offs[r + 1] - S->offs[r]), &S->starts[r], &S->ends[r], ws);
+        atomic_store_explicit(&S->done[s], 1, memory_order_release);
+    }
+    free(ws);
+    return NULL;
+}
+int vfo_count_reference_shape(const vfo_params *p, const uint8_t *bytes, const uint64_t *offs, int64_t nreads,
+                              int nworkers, vfo_table **out) {
+    vfo_derived d;
+    *out = NULL;
+    if (vfo_derive(p, &d)) return 1;
+    if (nworkers < 1) nworkers = 1;
+    if (nworkers > 256) nworkers = 256;
+    vfo_sets S;
+    S.p = p; S.d = &d; S.bytes = bytes; S.offs = offs; S.nreads = nreads; S.nsets = (nreads + kSet - 1) / kSet;
+    S.starts = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nreads + 1));
+    S.ends = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nreads + 1));
+    S.done = (atomic_int *)calloc((size_t)S.nsets + 1, sizeof(atomic_int));
+    atomic_init(&S.next_set, 0);
+    pthread_t th[256];
+    for (int k = 0; k < nworkers; ++k) pthread_create(&th[k], NULL, vfo_set_worker, &S);
+    vfo_table *t = vfo_table_new(1 << 12);
+    uint8_t *scratch = NULL; int64_t scap = 0;
+    for (int64_t s = 0; s < S.nsets; ++s) {             /* the calling thread: lib.rs:292-306, in input order */
+        while (!atomic_load_explicit(&S.done[s], memory_order_acquire)) sched_yield();
+        const int64_t lo = s * kSet, hi = lo + kSet < nreads ? lo + kSet : nreads;
+        for (int64_t r = lo; r < hi; ++r) {
+            const int64_t a = S.starts[r], b = S.ends[r];
+            if (a < 0 || b < 0 || !(a < b)) continue;   /* :288 */
+            const uint8_t *seq = bytes + offs[r];
+            if (p->skip_translation) {
+                if (vfo_valid_utf8(seq + a, b - a)) vfo_table_add(t, seq + a, b - a, 1);
+            } else {
+                const int64_t n = (int64_t)(offs[r + 1] - offs[r]);
+                if (n / 3 + 1 > scap) { scap = n / 3 + 64; scratch = (uint8_t *)realloc(scratch, (size_t)scap); }
+                const int64_t k = vfo_translate(seq + a, b - a, scratch);
+                if (k >= 0) vfo_table_add(t, scratch, k, 1);
+            }
+        }
+    }
+    for (int k = 0; k < nworkers; ++k) pthread_join(th[k], NULL);
+    free(scratch); free(S.starts); free(S.ends); free(S.done);
+    *out = t;
+    return 0;
 }
 
 /* ---------------------------------------------- FASTQ input chain (lib.rs:233-234, 271) */

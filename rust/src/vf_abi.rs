@@ -1,4 +1,4 @@
-//! `extern "C"` declarations of every entry point of include/vfind_hip.h (VF_ABI_VERSION 2), in the header's order.
+//! `extern "C"` declarations of every entry point of include/vfind_hip.h (VF_ABI_VERSION 3), in the header's order.
 //! tests/test_abi.py checks that this list and the header name the same functions.
 #![allow(dead_code)]
 use std::ffi::{c_char, c_int, c_void};
@@ -73,6 +73,7 @@ extern "C" {
     pub fn vf_comm_unique_id(id128: *mut c_void) -> c_int;
     pub fn vf_comm_init(ctx: *mut VfCtx, rank: c_int, world: c_int, id128: *const c_void) -> c_int;
     pub fn vf_table_allreduce(ctx: *mut VfCtx, root: c_int) -> c_int;
+    pub fn vf_wait_stream(ctx: *mut VfCtx, hip_stream: *mut c_void) -> c_int;
     pub fn vf_comm_local_create(world: c_int, out: *mut *mut c_void) -> c_int;
     pub fn vf_comm_local_destroy(group: *mut c_void);
     pub fn vf_comm_init_local(ctx: *mut VfCtx, rank: c_int, group: *mut c_void) -> c_int;

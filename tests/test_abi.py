@@ -152,3 +152,63 @@ def test_every_entry_point_sits_behind_the_barrier():
             assert "vf_guard(" in m.group(0), m.group(0)
             n += 1
     assert n >= 25
+
+
+def _c_layout(tmp_path):
+    """{struct: {field: (offset, size)}} as gcc lays out include/vfind_hip.h (tests/tools/abi_layout.c)"""
+    import subprocess
+    exe = str(tmp_path / "abi_layout")
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "tools", "abi_layout.c"), "-o", exe])
+    out = {}
+    for line in subprocess.check_output([exe], text=True).splitlines():
+        st, f, off, size = line.split()
+        out.setdefault(st, {})[f] = (int(off), int(size))
+    return out
+
+
+def test_ctypes_mirror_has_the_c_layout(tmp_path):
+    """size and every field offset of vf_params and vf_stats: the ctypes mirror against the C compiler's view of the header"""
+    from vfind_amd import _lib
+    lay = _c_layout(tmp_path)
+    for cname, mirror in (("vf_params", _lib.VfParams), ("vf_stats", _lib.VfStats)):
+        c = dict(lay[cname])
+        assert c.pop("sizeof")[0] == C.sizeof(mirror), cname
+        got = {}
+        for name, _typ in mirror._fields_:
+            d = getattr(mirror, name)
+            base = re.sub(r"\d+$", "", name) if name.startswith("dbg") else name      # dbg0..dbg3 mirror uint64_t dbg[4]
+            if base == "dbg":
+                o, sz = got.get("dbg", (d.offset, 0))
+                got["dbg"] = (min(o, d.offset), sz + d.size)
+            else:
+                got[name] = (d.offset, d.size)
+        assert got == c, (cname, {k: (got.get(k), c.get(k)) for k in set(got) | set(c) if got.get(k) != c.get(k)})
+
+
+def test_rust_structs_have_the_c_layout(tmp_path):
+    """rust/src/vf_abi.rs cannot be compiled here (no rustc): its #[repr(C)] VfParams / VfStats are parsed and laid out by the
+    C rules (natural alignment) and compared, field by field and in order, with the C compiler's view of the header"""
+    lay = _c_layout(tmp_path)
+    rs = open(os.path.join(ROOT, "rust", "src", "vf_abi.rs")).read()
+    sizes = {"u8": 1, "u32": 4, "i32": 4, "u64": 8, "f64": 8, "c_int": 4}
+    for rname, cname in (("VfParams", "vf_params"), ("VfStats", "vf_stats")):
+        m = re.search(r"#\[repr\(C\)\]\s*pub struct %s \{(.*?)\n\}" % rname, rs, re.S)
+        assert m, rname
+        at, fields, max_align = 0, {}, 1
+        for name, typ in re.findall(r"pub (\w+):\s*([^,\n]+?)\s*,", m.group(1)):
+            arr = re.match(r"\[(\w+);\s*(\d+)\]", typ)
+            if typ.startswith("*"):
+                size = align = 8
+            elif arr:
+                align = sizes[arr.group(1)]
+                size = align * int(arr.group(2))
+            else:
+                size = align = sizes[typ]
+            at = (at + align - 1) // align * align
+            fields[name] = (at, size)
+            at += size
+            max_align = max(max_align, align)
+        total = (at + max_align - 1) // max_align * max_align
+        c = dict(lay[cname])
+        assert c.pop("sizeof")[0] == total, rname
+        assert list(fields.items()) == sorted(c.items(), key=lambda kv: kv[1][0]), rname

@@ -526,6 +526,44 @@ def test_clear_switches_to_the_spare_table():
         assert e.finish_dict() == both
 
 
+def test_counts_are_exact_pass_after_pass_on_two_contexts_at_once():
+    """the count path under load (what scripts/count_stress.py does by hand): the same resident batch counted 30 times into a
+    cleared table, on two contexts driven by two threads at once - table kernels of both contexts, their count logs and their
+    clears interleave on the device.  Every pass of both contexts must give the oracle's table and account for every read the
+    kernels say they counted"""
+    import threading
+    import torch
+    from vfind_amd import Engine
+    from benchlib import synth as vsynth
+    ads = vsynth.adapters(0x5EED0002, 20)
+    gen = vsynth.Generator(0x5EED0002, ads, n_variants=30_000)
+    n = 300_000
+    rows_h, lens_h = gen.packed(0, n, 8)
+    data, offs = gen.ascii(0, n, 8)
+    want = oracle.count((data, offs), ads, n_threads=8)
+    rows = torch.from_numpy(rows_h).cuda()
+    lens = torch.from_numpy(lens_h.view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    bad = []
+
+    def run(tag):
+        with Engine(ads, table_slots=1 << 17) as e:
+            for it in range(30):
+                e.clear()
+                c0 = e.stats()["counted"]
+                e.process_device(rows.data_ptr(), gen.row_dwords, lens.data_ptr(), n)
+                e.sync()
+                got = e.finish_dict()
+                if got != want or sum(got.values()) != e.stats()["counted"] - c0:
+                    bad.append((tag, it, len(got), sum(got.values())))
+    th = [threading.Thread(target=run, args=(t,)) for t in ("a", "b")]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad, bad[:5]
+
+
 def test_count_log_both_modes_follow_the_oracle():
     """k_finish writes occurrences of known keys to the batch's count log; the log is applied by slot ranges (k_log_scatter +
     k_log_apply) or, for tables far larger than a batch, entry by entry (k_log_direct).  Both forced in turn (VFIND_COUNT_LOG,
@@ -1026,5 +1064,16 @@ def test_pinned_batch_api_round_trips_the_slots():
         h, rows, lens = e.batch_acquire(10, gen.row_dwords)
         with pytest.raises(ValueError, match="more reads"):
             e.batch_submit(h, 11)
+        # a handle is honoured once: the refused submit above gave the slot back, so the same handle is stale now - submitting
+        # or releasing it again, or handing it to another context, is refused without touching any slot
+        with pytest.raises(ValueError, match="not a batch handle"):
+            e.batch_submit(h, 1)
+        with pytest.raises(ValueError, match="not a batch handle"):
+            e.batch_release(h)
+        h2, rows, lens = e.batch_acquire(10, gen.row_dwords)
+        with Engine(ads, table_slots=1 << 10) as other:
+            with pytest.raises(ValueError, match="not a batch handle"):
+                other.batch_submit(h2, 1)
+        e.batch_release(h2)
         assert e.finish_dict() == oracle.count((data, offs), ads, n_threads=8)
         assert e.stats()["reads"] == n

@@ -98,3 +98,16 @@ def test_exact_semantics():
     assert oracle.find_exact("ACG", "ACGT") == -1
     assert oracle.find_exact("ACG", "") == 0             # empty needle matches at 0
     assert oracle.find_exact("", "A") == -1
+
+
+def test_reference_shape_count_equals_the_plain_count():
+    """oracle.count_reference_shape (W workers -> one serial reducer, lib.rs:271-306) gives the table oracle.count gives:
+    only the threading differs, and the bench times it as the CPU baseline in BASELINE.md 3's shape"""
+    from tests import synth
+    ads = ("GATCGGAAGAGCACACGTCT", "AGATCGGAAGAGCGTCGTGT")
+    reads = synth.make_reads(5, 9000, ads, L=150, sub=0.02, indel=0.004, dirty=0.02, n_variants=300)
+    want = oracle.count(reads, ads)
+    for w in (1, 3, 7):
+        assert oracle.count_reference_shape(reads, ads, n_workers=w) == want
+    assert oracle.count_reference_shape(reads, ads, n_workers=3, skip_translation=True) == oracle.count(reads, ads, skip_translation=True)
+    assert oracle.count_reference_shape([], ads) == {}

@@ -232,6 +232,11 @@ class Engine:
     def merge_from(self, src_ptr: int, nbytes: int):
         check(self._L.vf_table_merge(self._ctx, src_ptr, nbytes))
 
+    def wait_stream(self, hip_stream: int = 0):
+        """everything queued so far on the caller's stream (a raw hipStream_t, e.g. torch.cuda.current_stream().cuda_stream;
+        0 = the null stream) becomes a dependency of what this context does next with caller memory (vf_wait_stream)"""
+        check(self._L.vf_wait_stream(self._ctx, C.c_void_p(hip_stream or None)))
+
     def partition_sizes(self, world: int):
         """byte size of every owner's share of this table in an exchange between `world` GPUs"""
         out = (C.c_uint64 * world)()

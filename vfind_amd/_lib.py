@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libvfind_hip.so")
 
 VF_OK, VF_EINVAL, VF_EIO, VF_EFORMAT, VF_EDEVICE, VF_ECAPACITY, VF_ENOMEM = range(7)
-ABI_VERSION = 2          # VF_ABI_VERSION of include/vfind_hip.h
+ABI_VERSION = 3          # VF_ABI_VERSION of include/vfind_hip.h
 
 
 class VfParams(C.Structure):
@@ -67,6 +67,7 @@ SYMBOLS = [
     ("vf_table_export_size", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("vf_table_export", C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("vf_table_merge", C.c_int, [_P, _P, C.c_uint64]),
+    ("vf_wait_stream", C.c_int, [_P, _P]),
     ("vf_table_partition_sizes", C.c_int, [_P, C.c_uint32, _P]),
     ("vf_table_partition_export", C.c_int, [_P, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("vf_comm_unique_id", C.c_int, [_P]),
@@ -111,7 +112,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.vf_abi_version() != ABI_VERSION:
+        if L.vf_abi_version() != ABI_VERSION and not os.environ.get("VFIND_LIB_ANY_ABI"):      # (A/B runs against an older build)
             raise ImportError("libvfind_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -246,7 +246,8 @@ struct vf_ctx {
     hipEvent_t clear_event = nullptr;   // recorded on main_stream after each table clear
     hipEvent_t fin_event = nullptr;     // spare table: recorded after each table kernel, the next one waits for it (one at a time)
     std::mutex log_mu;                  // a batch's count log is applied on the main stream (run_packed)
-    bool fin_recorded = false;
+    std::atomic<bool> fin_recorded{false};
+    std::mutex fin_mu;                  // wait + launch + record of the table kernel: one submitter at a time, so the kernels really chain
     static constexpr int kMaxResLanes = 4;
     ResLane res[kMaxResLanes];   // vf_process_device_packed: batch k+1's scan/DP overlaps batch k's finish
     uint32_t n_res = 2, res_next = 0;
@@ -254,7 +255,7 @@ struct vf_ctx {
     // multi-GPU exchange
     DevBuf<uint64_t> d_part;            // k_owner_count output
     uint64_t part[2 * 64] = {};         // entries, key dwords per owner of the latest partition_counts
-    uint32_t part_world = 0;            // 0 = stale (the table changed since)
+    std::atomic<uint32_t> part_world{0};   // 0 = stale (the table changed since)
     void *comm = nullptr;               // ncclComm_t of vf_comm_init
     vf_local_group *local_group = nullptr;   // or the in-process group of vf_comm_init_local (not owned)
     int comm_rank = 0, comm_world = 1;
@@ -742,12 +743,17 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
     tab.chunk_row = chunk_row;
     // only the table kernels are ordered after the latest clear; scan and DP may overlap it
     if (count) HIP_TRY(hipStreamWaitEvent(st, c->clear_event, 0));
-    // with a spare table nothing else orders the table kernels of two batch lanes: side by side they take 40 % longer each
-    if (count && c->spare.valid && c->fin_recorded) HIP_TRY(hipStreamWaitEvent(st, c->fin_event, 0));
     // the previous log of this workspace has been applied (long ago, as a rule)
     if (count && ws.log_pending) { HIP_TRY(hipStreamWaitEvent(st, ws.log_applied, 0)); ws.log_pending = false; }
-    if (count) { Timed t(c, st, K_FIN); HIP_TRY(launch_finish(st, W, d_rows, d_lens, n, d_spans, c->skip_translation, tab, ws.count_log())); }
-    if (count && c->spare.valid) { HIP_TRY(hipEventRecord(c->fin_event, st)); c->fin_recorded = true; }
+    if (count) {
+        // With a spare table nothing else orders the table kernels of two batch lanes: side by side they take 40 % longer
+        // each.  Wait, launch and record under one lock: several submitting threads then chain their table kernels one
+        // behind the other instead of all waiting for the same earlier record.
+        std::lock_guard<std::mutex> fg(c->fin_mu);
+        if (c->spare.valid && c->fin_recorded.load()) HIP_TRY(hipStreamWaitEvent(st, c->fin_event, 0));
+        { Timed t(c, st, K_FIN); HIP_TRY(launch_finish(st, W, d_rows, d_lens, n, d_spans, c->skip_translation, tab, ws.count_log())); }
+        if (c->spare.valid) { HIP_TRY(hipEventRecord(c->fin_event, st)); c->fin_recorded.store(true); }
+    }
     if (count) {
         // The log is applied on the main stream: the batch's own stream goes on with its next batch, the other lane's
         // k_finish (which reads no count) starts beside it, and whatever reads or drops counts - clear, export, merge,
@@ -1054,17 +1060,33 @@ static int vf_batch_acquire_impl(vf_ctx *c, uint64_t n_reads, uint32_t W, vf_bat
     Slot *s = acquire_slot(c);                                  // owned by the caller until vf_batch_submit / _release
     int rc;
     if ((rc = wait_slot(c, s)) || (rc = s->h_rows.ensure((size_t)n_reads * W)) || (rc = s->h_lens.ensure(n_reads))) { release_slot(c, s); return rc; }
-    s->batch_cap = n_reads; s->batch_W = W;
+    { std::lock_guard<std::mutex> g(c->mu); s->batch_cap = n_reads; s->batch_W = W; }
     *rows = s->h_rows.p; *lens = s->h_lens.p;
     *out = reinterpret_cast<vf_batch *>(s);
     return VF_OK;
 }
 static int vf_batch_release_impl(vf_ctx *c, vf_batch *b);
 extern "C" int vf_batch_release(vf_ctx *c, vf_batch *b) { return vf_guard([&] { return vf_batch_release_impl(c, b); }); }
+// A batch handle is honoured once: it must be a slot of THIS context that vf_batch_acquire handed out and nobody has given
+// back yet.  A stale or doubly submitted handle used to release a slot another thread might just have acquired - two
+// writers on one pinned staging buffer and its stream.  Returns the slot, now owned by the caller, and the reads it was
+// acquired for; nullptr for any other handle (nothing touched).
+static Slot *batch_take(vf_ctx *c, vf_batch *b, uint64_t *cap) {
+    std::lock_guard<std::mutex> g(c->mu);
+    for (auto &x : c->slots)
+        if (reinterpret_cast<vf_batch *>(x.get()) == b) {
+            if (!x->busy || x->batch_cap == 0) return nullptr;
+            *cap = x->batch_cap;
+            x->batch_cap = 0;
+            return x.get();
+        }
+    return nullptr;
+}
 static int vf_batch_release_impl(vf_ctx *c, vf_batch *b) {
     if (!c || !b) return fail(VF_EINVAL, "null argument");
-    Slot *s = reinterpret_cast<Slot *>(b);
-    s->batch_cap = 0;
+    uint64_t cap = 0;
+    Slot *s = batch_take(c, b, &cap);
+    if (!s) return fail(VF_EINVAL, "not a batch handle of this context that is currently handed out");
     release_slot(c, s);
     return VF_OK;
 }
@@ -1072,9 +1094,11 @@ static int vf_batch_submit_impl(vf_ctx *c, vf_batch *b, uint64_t n);
 extern "C" int vf_batch_submit(vf_ctx *c, vf_batch *b, uint64_t n) { return vf_guard([&] { return vf_batch_submit_impl(c, b, n); }); }
 static int vf_batch_submit_impl(vf_ctx *c, vf_batch *b, uint64_t n) {
     if (!c || !b) return fail(VF_EINVAL, "null argument");
-    Slot *s = reinterpret_cast<Slot *>(b);
-    struct Rel { vf_ctx *c; Slot *s; ~Rel() { s->batch_cap = 0; release_slot(c, s); } } rel{c, s};
-    if (n > s->batch_cap) return fail(VF_EINVAL, "more reads than the batch was acquired for");
+    uint64_t cap = 0;
+    Slot *s = batch_take(c, b, &cap);
+    if (!s) return fail(VF_EINVAL, "not a batch handle of this context that is currently handed out");
+    struct Rel { vf_ctx *c; Slot *s; ~Rel() { release_slot(c, s); } } rel{c, s};      // (armed only for a handle that was ours to take)
+    if (n > cap) return fail(VF_EINVAL, "more reads than the batch was acquired for");
     if (n == 0) return VF_OK;
     const uint32_t W = s->batch_W;
     HIP_TRY(hipSetDevice(c->dev));
@@ -1206,6 +1230,20 @@ static int vf_table_clear_impl(vf_ctx *c) {
     int rc = table_clear_locked(c);
     if (rc == VF_OK && c->spare.valid && small) table_swap_spare(c);
     return rc;
+}
+
+static int vf_wait_stream_impl(vf_ctx *c, void *hip_stream);
+extern "C" int vf_wait_stream(vf_ctx *c, void *hip_stream) { return vf_guard([&] { return vf_wait_stream_impl(c, hip_stream); }); }
+static int vf_wait_stream_impl(vf_ctx *c, void *hip_stream) {
+    if (!c) return fail(VF_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(c->dev));
+    hipEvent_t ev = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    struct Drop { hipEvent_t e; ~Drop() { (void)hipEventDestroy(e); } } drop{ev};      // (destroyed once the waits below have consumed it)
+    HIP_TRY(hipEventRecord(ev, (hipStream_t)hip_stream));
+    HIP_TRY(hipStreamWaitEvent(c->main_stream, ev, 0));
+    for (auto &L : c->res) if (L.stream) HIP_TRY(hipStreamWaitEvent(L.stream, ev, 0));      // vf_process_device_packed reads caller memory on these
+    return VF_OK;
 }
 
 static uint64_t blob_bytes(uint64_t n, uint64_t arena_dw) { return 16 + n * 16 + arena_dw * 4; }

@@ -44,41 +44,82 @@ def allgather_blobs(send, nbytes: int, group=None) -> List[Tuple[object, int]]:
     return [(recv[r * cap:(r + 1) * cap], sizes_h[r]) for r in range(world)]
 
 
+def _padded(n: int) -> int:
+    return (n + 255) // 256 * 256
+
+
 def exchange_shares(engine, group=None, dst: int = 0):
     """The owner-partitioned reduce of the count tables with torch.distributed as the transport: every rank
-    buckets its entries by owner (vf_table_partition_export), bucket o goes to rank o, every owner clears its table and
-    merges the buckets it holds, and the owners' tables (disjoint key sets) are gathered and merged at `dst`.
-    The bytes move through all_gather of padded blobs, which every backend offers (gloo in the CPU-side rehearsal)."""
+    buckets its entries by owner (vf_table_partition_export), ONE all_to_all_single takes bucket o of every rank to rank o
+    and nowhere else (every entry crosses the wire once, as in the library's own RCCL exchange), every owner clears its
+    table and merges the buckets it holds, and a second all_to_all_single - all splits zero except towards `dst` - takes
+    the owners' tables (disjoint key sets) to `dst`, which merges them.  Works on nccl (device buffers) and on gloo (the
+    CPU-side rehearsal: the bytes are staged through host memory)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = torch.device("cuda", engine.device)
-    # The library writes and reads these buffers on its own (non-blocking) stream, torch on its current one: a buffer
-    # goes from one to the other only across a device synchronisation, and is allocated without a fill kernel (a
-    # torch.zeros still queued on torch's stream once landed on top of the exported bytes: lost entries on a cold GPU).
+    via_host = dist.get_backend(group) == "gloo"
+    wire = torch.device("cpu") if via_host else dev
+
+    def lib_waits_for_torch():
+        # buffers torch has just written go to the library only behind an event on torch's stream (vf_wait_stream); the
+        # other direction needs nothing: vf_table_export / _merge return when the library's stream is done with the buffer
+        engine.wait_stream(torch.cuda.current_stream(dev).cuda_stream)
+
+    def all_sizes(mine):                                         # [from][to], bytes
+        t = torch.tensor(mine, dtype=torch.int64, device=wire)
+        out = torch.empty(world * world, dtype=torch.int64, device=wire)
+        dist.all_gather_into_tensor(out, t, group=group)
+        return out.cpu().view(world, world).tolist()
+
+    def move(send, in_splits, out_splits):                       # device buffer -> device buffer through the group
+        recv = torch.empty(max(sum(out_splits), 1), dtype=torch.uint8, device=dev)[:sum(out_splits)]
+        s_w = send[:sum(in_splits)].to(wire) if via_host else send[:sum(in_splits)]
+        r_w = torch.empty(sum(out_splits), dtype=torch.uint8, device=wire) if via_host else recv
+        dist.all_to_all_single(r_w, s_w, out_splits, in_splits, group=group)
+        if via_host:
+            recv.copy_(r_w)
+        return recv
+
+    # buffers are allocated without a fill kernel (a torch.zeros still queued on torch's stream once landed on top of the
+    # exported bytes: lost entries on a cold GPU)
     sizes = engine.partition_sizes(world)
-    received = []
-    for owner in range(world):                                   # round o: everybody's bucket for owner o
-        send = torch.empty((sizes[owner] + 255) // 256 * 256, dtype=torch.uint8, device=dev)
-        engine.partition_export(world, owner, send.data_ptr(), send.numel())
-        parts = allgather_blobs(send, sizes[owner], group)
-        if owner == rank:
-            received = parts
-    torch.cuda.synchronize(dev)
+    pad = [_padded(x) for x in sizes]
+    send = torch.empty(max(sum(pad), 256), dtype=torch.uint8, device=dev)
+    lib_waits_for_torch()
+    at = 0
+    for owner in range(world):
+        engine.partition_export(world, owner, send.data_ptr() + at, pad[owner])
+        at += pad[owner]
+    table = all_sizes(sizes)
+    out_pad = [_padded(table[q][rank]) for q in range(world)]
+    recv = move(send, pad, out_pad)
+    lib_waits_for_torch()
     engine.clear()
-    for buf, nbytes in received:
-        engine.merge_from(buf.data_ptr(), nbytes)
+    at = 0
+    for q in range(world):
+        engine.merge_from(recv.data_ptr() + at, table[q][rank])
+        at += out_pad[q]
+    # shares to dst
     mine = engine.export_size()
-    send = torch.empty((mine + 255) // 256 * 256, dtype=torch.uint8, device=dev)
-    engine.export_to(send.data_ptr(), send.numel())
-    parts = allgather_blobs(send, mine, group)
-    torch.cuda.synchronize(dev)
+    shares = all_sizes([mine if q == dst and rank != dst else 0 for q in range(world)])
+    send = torch.empty(max(_padded(mine), 256), dtype=torch.uint8, device=dev)
+    lib_waits_for_torch()
+    if rank != dst:
+        engine.export_to(send.data_ptr(), send.numel())
+    in_splits = [(_padded(mine) if q == dst and rank != dst else 0) for q in range(world)]
+    out_splits = [(_padded(shares[q][dst]) if rank == dst else 0) for q in range(world)]
+    recv = move(send, in_splits, out_splits)
     if rank == dst:
-        for r, (buf, nbytes) in enumerate(parts):
-            if r != rank:
-                engine.merge_from(buf.data_ptr(), nbytes)
+        lib_waits_for_torch()
+        at = 0
+        for q in range(world):
+            if q != rank:
+                engine.merge_from(recv.data_ptr() + at, shares[q][dst])
+            at += out_splits[q]
 
 
 def allreduce_local(engines, root: int = 0):
