@@ -52,10 +52,10 @@ def tie_sensitive_fraction(data, offs, ads, oracle, budget_s=8.0, max_reads=400)
                     "kernel == oracle there under tie policy P, oracle == parasail is unpinned"}
 
 
-def other_config_leg(vfind_amd, synth, oracle, name, device, host_threads, n, L, adapter_len, variants, sub_rate, indel_rate, seed,
+def other_config_leg(vfind_amd, synth, oracle, name, device, host_threads, n, n_parity, L, adapter_len, variants, sub_rate, indel_rate, seed,
                      steps=10, warmup=2):
-    """one of BASELINE.json's other shapes on this GPU, resident in HBM like the headline: its own ms_per_step and path roofline,
-    and the table left by the last step compared - whole - with the CPU oracle's over the same reads"""
+    """one of BASELINE.json's other shapes on this GPU, resident in HBM like the headline: its own ms_per_step and path roofline
+    over n reads a step, and the table of the first n_parity of those reads compared - whole - with the CPU oracle's"""
     import numpy as np
     import torch
     ads = synth.adapters(seed, adapter_len)
@@ -85,8 +85,10 @@ def other_config_leg(vfind_amd, synth, oracle, name, device, host_threads, n, L,
         eng.sync()
         dt = time.perf_counter() - t0
         st = eng.stats()
+        eng.clear()
+        eng.process_device(rows.data_ptr(), gen.row_dwords, lens.data_ptr(), n_parity)
         got = eng.finish_dict()
-        data, offs = gen.ascii(0, n, host_threads)
+        data, offs = gen.ascii(0, n_parity, host_threads)
         tq = time.perf_counter()
         want = oracle.count((data, offs), ads, n_threads=host_threads)
         cpu_dt = time.perf_counter() - tq
@@ -100,14 +102,34 @@ def other_config_leg(vfind_amd, synth, oracle, name, device, host_threads, n, L,
                 "roofline_path": {"bound": "hbm", "achieved": round(gbps, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                   "frac": round(gbps / HBM_PEAK_GBPS, 6), "alg_bytes_per_read": b_alg(L)},
                 "alignments_per_read": round((st["dp_prefix"] + st["dp_suffix"]) / steps / n, 3),
-                "parity_full_table": True, "table_rows": len(got),
-                "cpu_oracle_M_reads_per_s": round(n / cpu_dt / 1e6, 3), "cpu_threads": host_threads}
+                "parity_full_table": True, "parity_reads": n_parity, "table_rows": len(got),
+                "cpu_oracle_M_reads_per_s": round(n_parity / cpu_dt / 1e6, 3), "cpu_threads": host_threads}
     finally:
         eng.close()
         del rows, lens
 
 
-def pcie_inclusive_leg(vfind_amd, gen, ads, n, L, device, slots, host_threads, rounds=3, queue_len=8):
+def h2d_raw_gbps(hip_host_ptrs, nbytes, device):
+    """raw rate of the link out of the library's own page-locked staging, same process, same box: the batches' buffers copied
+    to a scratch device buffer with nothing else going on (what `link_GBps` of the leg is read against)"""
+    import ctypes as C
+    import torch
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", device))
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    tot = 0
+    for _ in range(3):
+        for p in hip_host_ptrs:
+            if hip.hipMemcpyAsync(dst.data_ptr(), p, nbytes, 1, None) != 0:
+                return None
+            tot += nbytes
+    torch.cuda.synchronize(device)
+    return round(tot / (time.perf_counter() - t0) / 1e9, 2)
+
+
+def pcie_inclusive_leg(vfind_amd, gen, ads, n, L, device, slots, host_threads, rounds=6, queue_len=8):
     """reads/s with the batches in page-locked HOST memory when the clock starts: vf_batch_acquire / vf_batch_submit, queue_len
     slots, hipMemcpyAsync of batch k + 1 overlapped with the kernels of batch k.  The staging is filled once (the host decoder's
     own speed is not part of this leg) and re-submitted `rounds` times."""
@@ -115,9 +137,18 @@ def pcie_inclusive_leg(vfind_amd, gen, ads, n, L, device, slots, host_threads, r
     eng = vfind_amd.Engine(ads, device=device, table_slots=slots, arena_bytes=1 << 30, queue_len=queue_len)
     try:
         W = gen.row_dwords
+        stag = []
         for k in range(queue_len):                       # fill every slot's staging once
             h, r, l = eng.batch_acquire(nb, W)
             gen.packed_into(k * nb, nb, r.ctypes.data, l.ctypes.data, host_threads)
+            stag.append(r.ctypes.data)
+            eng.batch_submit(h, nb)
+        eng.sync()
+        raw = h2d_raw_gbps(stag, nb * W * 4, device)
+        # two untimed rounds at full submit rate: with every slot in flight the table grows once to the size that holds a
+        # whole pipeline of possibly-new keys (a one-off rehash that a long job does not notice and a 50 ms window would)
+        for _ in range(2 * queue_len):
+            h, r, l = eng.batch_acquire(nb, W)
             eng.batch_submit(h, nb)
         eng.sync()
         eng.clear()
@@ -129,8 +160,10 @@ def pcie_inclusive_leg(vfind_amd, gen, ads, n, L, device, slots, host_threads, r
         dt = time.perf_counter() - t0
         reads = rounds * queue_len * nb
         row_b = W * 4 + 2
-        return {"value": round(reads / dt / 1e6, 2), "unit": "M reads/s", "link_GBps": round(reads * row_b / dt / 1e9, 2),
-                "link_peak_GBps": 63.0, "batches": rounds * queue_len, "reads_per_batch": nb, "queue_len": queue_len,
+        link = reads * row_b / dt / 1e9
+        return {"value": round(reads / dt / 1e6, 2), "unit": "M reads/s", "link_GBps": round(link, 2),
+                "link_peak_GBps": 63.0, "h2d_raw_GBps": raw, "frac_of_raw": None if not raw else round(link / raw, 3),
+                "batches": rounds * queue_len, "reads_per_batch": nb, "queue_len": queue_len,
                 "what": "packed reads in the library's page-locked staging -> hipMemcpyAsync -> whole device path, table not cleared between batches"}
     finally:
         eng.close()
@@ -190,7 +223,8 @@ def main():
     ap.add_argument("--table-slots", type=int, default=0, help="count-table slots (0 = 2x the variant library, power of two)")
     ap.add_argument("--no-extras", action="store_true", help="skip the legs beside the headline: result build, PCIe-inclusive, end-to-end FASTQ, tie-sensitive fraction")
     ap.add_argument("--e2e-reads", type=int, default=2_000_000, help="reads of the gzip FASTQ file of the end-to-end leg")
-    ap.add_argument("--other-config-reads", type=int, default=2_000_000, help="resident reads of each of the other BASELINE shapes (extras)")
+    ap.add_argument("--other-config-reads", type=int, default=8_000_000, help="resident reads per step of each of the other BASELINE shapes (extras)")
+    ap.add_argument("--other-config-parity-reads", type=int, default=2_000_000, help="reads of those shapes whose whole table is compared with the CPU oracle")
     ap.add_argument("--merge-transport", default="auto", choices=["auto", "rccl", "torch"],
                     help="final table reduce: rccl = the library's own exchange (vf_comm_init / vf_table_allreduce), torch = the same "
                          "algorithm with torch.distributed moving the bytes; auto = rccl when the backend is nccl")
@@ -416,11 +450,11 @@ def main():
         if not args.no_parity and not args.no_cpu_baseline:
             # BASELINE.json configs[3] and configs[4] in shape (their read counts are 8-GPU jobs), each with its whole table checked
             from oracle import oracle as _oracle
-            oc_n = args.other_config_reads
+            oc_n, oc_p = args.other_config_reads, min(args.other_config_reads, args.other_config_parity_reads)
             extras["other_configs"] = {
-                "cfg4_shape_dp_on_every_read": other_config_leg(vfind_amd, synth, _oracle, "cfg 4 shape", local_rank, host_threads, oc_n, 150, 20,
+                "cfg4_shape_dp_on_every_read": other_config_leg(vfind_amd, synth, _oracle, "cfg 4 shape", local_rank, host_threads, oc_n, oc_p, 150, 20,
                                                                 1_000_000, 0.15, 0.0, 0x5EED0004),
-                "cfg5_shape_300bp_30bp_adapters": other_config_leg(vfind_amd, synth, _oracle, "cfg 5 shape", local_rank, host_threads, oc_n, 300, 30,
+                "cfg5_shape_300bp_30bp_adapters": other_config_leg(vfind_amd, synth, _oracle, "cfg 5 shape", local_rank, host_threads, oc_n, oc_p, 300, 30,
                                                                    10_000_000, 0.005, 0.0005, 0x5EED0005),
             }
 
@@ -487,7 +521,8 @@ def main():
         steps = max(args.steps, 1)
         tasks = (st["dp_prefix"] + st["dp_suffix"]) / steps / 2
         kern = {        # (event ms summed, launches, algorithmic bytes per launch, steps the sum covers)
-            "scan": (st_k["ms_scan"], st_k["launches_scan"], n * b_alg(L), k_steps),
+            "scan": ((st["ms_scan"], st["launches_scan"], n * b_alg(L), steps) if ev_mode == 2 and st["launches_scan"] else
+                     (st_k["ms_scan"], st_k["launches_scan"], n * b_alg(L), k_steps)),                                 # timed region (mode 2)
             "filter": (st_k["ms_filter"], st_k["launches_filter"], tasks * (row_b + 10), k_steps),
             "dp_window": (st_k["ms_dp_window"], st_k["launches_dp_window"], tasks * (row_b + 14), k_steps),
             "dp_rest": (st_k["ms_dp_rest"], st_k["launches_dp_rest"], tasks * (row_b + 14), k_steps),
@@ -524,11 +559,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(bytes_per_launch),
-                         "events": "inside the timed region" if (dom == "finish" or ev_mode == 1) else "pass after the timed region"},
+                         "events": "inside the timed region" if (dom in ("finish", "scan") or ev_mode == 1) else "pass after the timed region"},
             "roofline_path": {"bound": "hbm", "achieved": round(path_gbps, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": round(path_gbps / HBM_PEAK_GBPS, 6), "alg_bytes_per_read": b_alg(L),
                               "kernel_ms_per_step": {k: round(v[0] / v[3], 4) for k, v in kern.items()},
-                              "kernel_ms_source": "finish: HIP events inside the timed region; others: the same steps again right after it, every launch bracketed" if ev_mode == 2 else "HIP events inside the timed region"},
+                              "kernel_ms_source": "scan, finish: HIP events inside the timed region; others: the same steps again right after it, every launch bracketed" if ev_mode == 2 else "HIP events inside the timed region"},
             # per kernel against the same HBM peak, and the ceilings that bind before HBM does: the
             # integer VALU if every read needed both alignments (2 L m cells at the measured 11.45 instructions per
             # cell, 256 CUs x 4 SIMDs x one wave64 instruction per ~2.3 cycles at 2.1 GHz), and PCIe for streamed input

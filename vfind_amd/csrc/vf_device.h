@@ -186,6 +186,7 @@ hipError_t launch_frame_pack(hipStream_t s, int W, const uint8_t *text, const ui
                              uint16_t *lens, uint32_t *gen_start, uint32_t *gen_len, uint32_t *info, bool all_generic);
 struct ClearRegions { void *p[4]; uint64_t bytes[4]; };   // 16-byte aligned starts, sizes multiples of 4
 hipError_t launch_clear(hipStream_t s, const ClearRegions &cr);
+hipError_t launch_peek(hipStream_t s, const void *d_src, void *h_dst, uint32_t n_dwords);   // <= 64 dwords, device -> page-locked host, no copy engine
 // G = 0: the whole table; otherwise the entries owned by `owner` of G in the multi-GPU exchange
 hipError_t launch_export(hipStream_t s, Table t, uint64_t *out_refs, uint64_t *out_counts, uint32_t *out_arena, uint32_t G, uint32_t owner);
 hipError_t launch_owner_count(hipStream_t s, Table t, uint32_t G, uint64_t *out);      // out[2 G]: entries, key dwords per owner (zeroed by the caller)

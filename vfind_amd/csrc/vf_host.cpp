@@ -166,7 +166,8 @@ struct ResLane {                 // one of the in-order lanes vf_process_device_
     PinBuf<uint64_t> h_entries;  // table entry count as of this lane's latest finished batch
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
-    bool in_flight = false;
+    std::atomic<bool> in_flight{false};
+    std::atomic<uint64_t> inflight_reads{0};   // reads of the batch `done` stands for (capacity_refresh)
     uint32_t chunk_row = 0;
     Workspace ws;
 };
@@ -177,7 +178,9 @@ struct Slot {
     hipEvent_t done = nullptr;
     uint32_t index = 0;          // chunk-state row of this slot's stream
     bool busy = false;           // owned by a submitting thread
-    bool in_flight = false;      // event recorded, not yet waited
+    std::atomic<bool> in_flight{false};      // event recorded, not yet waited
+    std::atomic<uint64_t> inflight_reads{0};  // reads of the batch `done` stands for (capacity_refresh)
+    std::atomic<bool> cap_pending{false};     // those reads still count as possible new keys (capacity_retire takes them off)
     // fast path staging
     PinBuf<uint32_t> h_rows; PinBuf<uint16_t> h_lens;
     DevBuf<uint32_t> d_rows; DevBuf<uint16_t> d_lens;
@@ -273,6 +276,10 @@ struct vf_ctx {
     std::shared_mutex table_mu;
     std::mutex cap_mu;                          // guards the two counters below
     uint64_t upper_entries = 0;                 // entries at the last exact count + every read submitted since
+    // the same bound without the drain: the largest entry count a FINISHED batch has brought back (the counter only grows, so
+    // the batch that finished last brought one that covers every finished batch) + the reads of the batches that have not
+    // been seen to finish (each may still add a key)
+    uint64_t known_entries = 0, pending_reads = 0;
     uint64_t unenqueued = 0;                    // reads of submitters between their capacity check and their enqueue
     uint64_t upper_arena = 0, unenqueued_arena = 0;   // the same pair for key-arena dwords
     std::mutex err_mu;
@@ -586,7 +593,7 @@ static int resolve_events(vf_ctx *c) {
 }
 struct Timed {
     vf_ctx *c; hipStream_t s; int kind; hipEvent_t a = nullptr, b = nullptr; bool on;
-    Timed(vf_ctx *c_, hipStream_t s_, int k) : c(c_), s(s_), kind(k), on(c_->profiling == 1 || (c_->profiling == 2 && k == K_FIN)) {
+    Timed(vf_ctx *c_, hipStream_t s_, int k) : c(c_), s(s_), kind(k), on(c_->profiling == 1 || (c_->profiling == 2 && (k == K_FIN || k == K_SCAN))) {
         if (on) {
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
             (void)hipEventRecord(a, s);
@@ -624,7 +631,16 @@ static int table_grow_locked(vf_ctx *c, bool use_unenqueued, uint64_t extra, uin
     if ((rc = sync_all_streams(c))) return rc;
     uint64_t h[C_NUM];
     HIP_TRY(hipMemcpy(h, c->t_counters.p, sizeof(h), hipMemcpyDeviceToHost));
-    if (use_unenqueued) { std::lock_guard<std::mutex> g(c->cap_mu); extra = c->unenqueued; extra_arena = c->unenqueued_arena; }
+    if (use_unenqueued) {
+        // a streaming submitter ran out of (conservatively counted) room: make room for what is on its way in AND for a
+        // full pipeline behind it - every slot's latest batch - so that the bound capacity_refresh can give without
+        // draining the streams fits from now on.  Sizing for the reads on their way in alone left a table that was a tenth
+        // full and a drain of every stream every two or three batches (memory is not what an MI355X is short of).
+        uint64_t pipeline = 0;
+        for (auto &s : c->slots) pipeline += s->inflight_reads.load();
+        std::lock_guard<std::mutex> g(c->cap_mu);
+        extra = c->unenqueued + pipeline; extra_arena = c->unenqueued_arena;
+    }
     // key arena: offsets stay valid, so growing is a copy
     if (extra_arena) {
         uint64_t cap = c->arena_dwords;
@@ -660,7 +676,13 @@ static int table_grow_locked(vf_ctx *c, bool use_unenqueued, uint64_t extra, uin
         c->tab = to;
         HIP_TRY(hipMemcpy(h, c->t_counters.p, sizeof(h), hipMemcpyDeviceToHost));
     }
-    { std::lock_guard<std::mutex> g(c->cap_mu); c->upper_entries = h[C_ENTRIES] + c->unenqueued; c->upper_arena = h[C_ARENA_TOP] + c->unenqueued_arena; }
+    // (every stream has been drained: nothing is in flight, the bound is exact again)
+    {
+        std::lock_guard<std::mutex> g(c->cap_mu);
+        c->upper_entries = h[C_ENTRIES] + c->unenqueued; c->upper_arena = h[C_ARENA_TOP] + c->unenqueued_arena;
+        c->known_entries = h[C_ENTRIES]; c->pending_reads = 0;
+        for (auto &s : c->slots) s->cap_pending = false;
+    }
     for (auto &s : c->slots) if (s->h_entries.p) *s->h_entries.p = h[C_ENTRIES];
     for (auto &L : c->res) if (L.h_entries.p) *L.h_entries.p = h[C_ENTRIES];
     return VF_OK;
@@ -686,6 +708,37 @@ static inline uint64_t arena_need(const vf_ctx *c, uint32_t len) {
     const uint64_t nd = c->skip_translation ? (len + 15) / 16 : (len / 3 + 3) / 4;
     return nd > kChunk / 4 ? nd + kChunk : nd + nd / 3 + 1;
 }
+// A batch has been enqueued on a slot: its reads count as possible new keys until the batch is seen to have finished.
+static void capacity_note_enqueued(vf_ctx *c, Slot *s, uint64_t n) {
+    s->inflight_reads = n;
+    { std::lock_guard<std::mutex> g(c->cap_mu); c->pending_reads += n; }
+    s->cap_pending = true;
+    s->in_flight = true;
+}
+// ... and has finished (its `done` event is complete): the entry count it brought back stands for its reads from now on
+static void capacity_retire(vf_ctx *c, Slot *s) {
+    if (!s->cap_pending.exchange(false)) return;
+    std::lock_guard<std::mutex> g(c->cap_mu);
+    const uint64_t n = s->inflight_reads.load();
+    c->pending_reads -= std::min(c->pending_reads, n);
+    if (s->h_entries.p && *s->h_entries.p > c->known_entries) c->known_entries = *s->h_entries.p;
+}
+// The conservative entry count brought up to date WITHOUT draining the streams and without any device work: every batch
+// whose event has completed is retired (no wait: hipEventQuery), and the bound is the largest entry count a finished batch
+// brought back + the reads still in flight + the reads on their way in.  The running bound otherwise grows by a batch with
+// every submit and sent the submitter into table_grow_locked - a drain of every stream - every two or three batches
+// although the table was a tenth full: the copies of the PCIe-inclusive leg ran in pairs with 0.6 ms of idle link behind
+// each pair.  (Asking the device instead - a tiny kernel or copy on a stream of its own - waits behind whichever slot
+// shares its hardware queue, and that slot's kernels wait for its 47 MB copy: 5 ms.)
+static bool capacity_refresh(vf_ctx *c, uint64_t *upper_out) {
+    for (auto &L : c->res) if (L.stream && L.in_flight.load() && hipEventQuery(L.done) != hipSuccess) return false;   // resident batches are not in these books
+    for (auto &s : c->slots) if (s->cap_pending.load() && s->in_flight.load() && hipEventQuery(s->done) == hipSuccess) capacity_retire(c, s.get());
+    std::lock_guard<std::mutex> g(c->cap_mu);
+    const uint64_t fresh = c->known_entries + c->pending_reads + c->unenqueued;
+    if (fresh < c->upper_entries) c->upper_entries = fresh;
+    *upper_out = c->upper_entries;
+    return true;
+}
 static int reserve_capacity(vf_ctx *c, CapacityTicket &t, uint64_t n, uint64_t arena) {
     uint64_t up, upa;
     {
@@ -694,7 +747,9 @@ static int reserve_capacity(vf_ctx *c, CapacityTicket &t, uint64_t n, uint64_t a
         c->unenqueued += n; c->unenqueued_arena += arena;
         up = (c->upper_entries += n); upa = (c->upper_arena += arena);
     }
-    if (up * 2 <= c->table_slots && (!arena || upa + arena_slack(c) <= c->arena_dwords)) return VF_OK;
+    const bool arena_ok = !arena || upa + arena_slack(c) <= c->arena_dwords;
+    if (up * 2 <= c->table_slots && arena_ok) return VF_OK;
+    if (arena_ok && capacity_refresh(c, &up) && up * 2 <= c->table_slots) return VF_OK;
     return table_grow_locked(c, true, 0);
 }
 
@@ -771,7 +826,7 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
         ws.log_pending = true;
     }
     // the entry count rides back with the batch: the host grows the table between batches when it fills
-    if (count && h_entries) HIP_TRY(hipMemcpyAsync(h_entries, c->t_counters.p + C_ENTRIES, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    if (count && h_entries) HIP_TRY(launch_peek(st, c->t_counters.p + C_ENTRIES, h_entries, 2));
     return VF_OK;
 }
 
@@ -799,7 +854,7 @@ static int run_generic(vf_ctx *c, Slot &s, uint64_t ng, uint64_t nbytes, uint32_
     tab.chunk_row = s.index;
     if (count) HIP_TRY(hipStreamWaitEvent(s.stream, c->clear_event, 0));
     { Timed t(c, s.stream, K_GEN); HIP_TRY(launch_generic(s.stream, s.d_gbytes.p, s.d_goffs.p, ng, gp, ds, de, s.d_gws.p, threads, rows, tab)); }
-    if (count && s.h_entries.p) HIP_TRY(hipMemcpyAsync(s.h_entries.p, c->t_counters.p + C_ENTRIES, sizeof(uint64_t), hipMemcpyDeviceToHost, s.stream));
+    if (count && s.h_entries.p) HIP_TRY(launch_peek(s.stream, c->t_counters.p + C_ENTRIES, s.h_entries.p, 2));
     return VF_OK;
 }
 
@@ -848,6 +903,7 @@ static int collect_text_result(vf_ctx *c, Slot *s) {
 static int wait_slot(vf_ctx *c, Slot *s) {
     if (s->in_flight) {
         HIP_TRY(hipEventSynchronize(s->done));
+        capacity_retire(c, s);
         s->in_flight = false;
     }
     return collect_text_result(c, s);
@@ -950,7 +1006,7 @@ static int submit_chunk(vf_ctx *c, const uint8_t *base, const ReadRef *reads, ui
         }
     } else {
         HIP_TRY(hipEventRecord(s->done, s->stream));
-        s->in_flight = true;
+        capacity_note_enqueued(c, s, n);
     }
     return VF_OK;
 }
@@ -1007,14 +1063,16 @@ static int vf_submit_packed_impl(vf_ctx *c, const uint32_t *rows, uint32_t W, co
     HIP_TRY(hipSetDevice(c->dev));
     for (uint64_t lo = 0; lo < n; lo += c->batch_reads) {
         const uint64_t m = std::min<uint64_t>(c->batch_reads, n - lo);
-        for (uint64_t i = 0; i < m; ++i) if (lens[lo + i] > W * 16u) return fail(VF_EINVAL, "read length exceeds row");
+        uint16_t mx = 0;
+        for (uint64_t i = 0; i < m; ++i) mx = lens[lo + i] > mx ? lens[lo + i] : mx;      // (vectorised: see vf_batch_submit)
+        if (mx > W * 16u) return fail(VF_EINVAL, "read length exceeds row");
         Slot *s = acquire_slot(c);
         struct Rel { vf_ctx *c; Slot *s; ~Rel() { release_slot(c, s); } } rel{c, s};
         int rc;
         if ((rc = wait_slot(c, s))) return rc;
         CapacityTicket ticket{c};
         uint64_t need = 0;
-        for (uint64_t i = 0; i < m; ++i) need += arena_need(c, lens[lo + i]);
+        if (arena_need(c, mx) != 0) for (uint64_t i = 0; i < m; ++i) need += arena_need(c, lens[lo + i]);
         if ((rc = reserve_capacity(c, ticket, m, need))) return rc;
         std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
         if ((rc = s->h_rows.ensure((size_t)m * W))) return rc;
@@ -1037,7 +1095,7 @@ static int vf_submit_packed_impl(vf_ctx *c, const uint32_t *rows, uint32_t W, co
         HIP_TRY(hipMemcpyAsync(s->d_lens.p, s->h_lens.p, m * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
         if ((rc = run_packed(c, s->stream, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, m, s->ws.spans.p, true, s->h_entries.p))) return rc;
         HIP_TRY(hipEventRecord(s->done, s->stream));
-        s->in_flight = true;
+        capacity_note_enqueued(c, s, m);
         c->n_reads += m;
     }
     return VF_OK;
@@ -1102,21 +1160,35 @@ static int vf_batch_submit_impl(vf_ctx *c, vf_batch *b, uint64_t n) {
     if (n == 0) return VF_OK;
     const uint32_t W = s->batch_W;
     HIP_TRY(hipSetDevice(c->dev));
+    // longest read first, in a loop the compiler vectorises: the per-read form of this check (a call and two branches a
+    // read) took 0.5 ms of host time per 1.25 M-read batch - more than half the batch's copy over the link, and the single
+    // submitting thread of the PCIe-inclusive leg paced the link at 30 of 56 GB/s (profiles/r03_pcie_timeline.md)
     uint64_t need = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        if (s->h_lens.p[i] > W * 16u) return fail(VF_EINVAL, "read length exceeds row");
-        need += arena_need(c, s->h_lens.p[i]);
+    {
+        const uint16_t *hl = s->h_lens.p;
+        uint16_t mx = 0;
+        for (uint64_t i = 0; i < n; ++i) mx = hl[i] > mx ? hl[i] : mx;
+        if (mx > W * 16u) return fail(VF_EINVAL, "read length exceeds row");
+        if (arena_need(c, mx) != 0)                       // only reads long enough for an arena key cost anything
+            for (uint64_t i = 0; i < n; ++i) need += arena_need(c, hl[i]);
     }
     int rc;
+    static const bool dbg_t = [] { const char *v = getenv("VFIND_DEBUG_SUBMIT"); return v && atoi(v) != 0; }();      // host time of each phase, stderr
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = dbg_t ? now() : 0;
     CapacityTicket ticket{c};
     if ((rc = reserve_capacity(c, ticket, n, need))) return rc;
+    const double t1 = dbg_t ? now() : 0;
     std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
     if ((rc = s->d_rows.ensure((size_t)n * W)) || (rc = s->d_lens.ensure(n)) || (rc = s->ws.ensure(n))) return rc;
+    const double t2 = dbg_t ? now() : 0;
     HIP_TRY(hipMemcpyAsync(s->d_rows.p, s->h_rows.p, (size_t)n * W * 4, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->d_lens.p, s->h_lens.p, n * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
+    const double t3 = dbg_t ? now() : 0;
     if ((rc = run_packed(c, s->stream, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, n, s->ws.spans.p, true, s->h_entries.p))) return rc;
+    if (dbg_t) fprintf(stderr, "[submit] capacity %.2f ensure %.2f copies %.2f kernels %.2f ms\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);
     HIP_TRY(hipEventRecord(s->done, s->stream));
-    s->in_flight = true;
+    capacity_note_enqueued(c, s, n);
     c->n_reads += n;
     return VF_OK;
 }
@@ -1138,6 +1210,7 @@ static int vf_process_device_packed_impl(vf_ctx *c, const void *d_rows, uint32_t
     short2 *spans = d_spans ? (short2 *)d_spans : L.ws.spans.p;
     if ((rc = run_packed(c, L.stream, L.chunk_row, L.ws, (const uint32_t *)d_rows, (int)W, (const uint16_t *)d_lens, n, spans, true, L.h_entries.p))) return rc;
     HIP_TRY(hipEventRecord(L.done, L.stream));
+    L.inflight_reads = n;
     L.in_flight = true;
     c->n_reads += n;
     // diagnosis: tasks per filter class of this batch (synchronises the lane; never set in a measurement)
@@ -1181,6 +1254,7 @@ static int vf_sync_impl(vf_ctx *c) {
     for (auto &s : c->slots) {
         // a slot is only touched by its owner between acquire/release; here nobody may be submitting
         HIP_TRY(hipStreamSynchronize(s->stream));
+        capacity_retire(c, s.get());
         s->in_flight = false;
         (void)collect_text_result(c, s.get());
     }
@@ -1213,7 +1287,12 @@ static int vf_table_clear_impl(vf_ctx *c) {
     for (auto &L : c->res)
         if (L.in_flight) HIP_TRY(hipStreamWaitEvent(c->main_stream, L.done, 0));
     std::unique_lock<std::shared_mutex> table_lock(c->table_mu);        // the table in use changes hands below
-    { std::lock_guard<std::mutex> g(c->cap_mu); c->upper_entries = c->unenqueued; c->upper_arena = c->unenqueued_arena; }
+    {
+        std::lock_guard<std::mutex> g(c->cap_mu);
+        c->upper_entries = c->unenqueued; c->upper_arena = c->unenqueued_arena;
+        c->known_entries = 0; c->pending_reads = 0;                       // (batches still in flight count into the table being dropped)
+        for (auto &s : c->slots) s->cap_pending = false;
+    }
     for (auto &s : c->slots) if (s->h_entries.p) *s->h_entries.p = 0;  // (growth hints of the table being dropped)
     for (auto &L : c->res) if (L.h_entries.p) *L.h_entries.p = 0;
     c->part_world = 0;
@@ -1352,6 +1431,7 @@ static int vf_table_merge_impl(vf_ctx *c, const void *d_blob, uint64_t nbytes) {
         }
         std::lock_guard<std::mutex> g(c->cap_mu);
         c->upper_entries += hdr[0]; c->upper_arena += hdr[1];
+        c->known_entries += hdr[0];
     }
     std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
     c->part_world = 0;
@@ -1942,7 +2022,7 @@ int vf_internal_submit_text(vf_ctx *c, const TextSpan *spans, size_t n_spans, bo
         HIP_TRY(hipMemcpyAsync(s->d_text.p, s->h_text.p, total, hipMemcpyHostToDevice, s->stream));
     }
     HIP_TRY(launch_line_index(s->stream, s->d_text.p, total, s->d_tile_cnt.p, s->d_tile_off.p, s->d_line_end.p, s->d_info.p));
-    HIP_TRY(hipMemcpyAsync(s->h_info.p, s->d_info.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(launch_peek(s->stream, s->d_info.p, s->h_info.p, 2));
     HIP_TRY(hipStreamSynchronize(s->stream));
     const uint32_t n_lines = s->h_info.p[0], max_line = s->h_info.p[1];
     if (n_lines % 4u) return fail(VF_EFORMAT, "malformed FASTQ: truncated record");
@@ -1978,9 +2058,9 @@ int vf_internal_submit_text(vf_ctx *c, const TextSpan *spans, size_t n_spans, bo
         Timed t(c, s->stream, K_GEN);
         HIP_TRY(launch_generic_indexed(s->stream, s->d_text.p, s->d_gen_start.p, s->d_gen_len.p, s->d_info.p + 3, gp, s->d_gws.p, threads, rows, tab));
     }
-    HIP_TRY(hipMemcpyAsync(s->h_info.p, s->d_info.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(launch_peek(s->stream, s->d_info.p, s->h_info.p, 4));
     HIP_TRY(hipEventRecord(s->done, s->stream));
-    s->in_flight = true;
+    capacity_note_enqueued(c, s, n);
     s->text_pending = true;
     return VF_OK;
 }

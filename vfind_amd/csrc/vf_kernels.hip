@@ -3075,6 +3075,19 @@ extern "C" int vf_debug_dp_trace(uint64_t *out) {          // diagnosis build: 2
 }
 #endif
 
+// A few words of device memory written straight into page-locked host memory by a one-wave kernel.  An 8-byte
+// hipMemcpyAsync device-to-host goes through the copy engine's queue, in order behind every 47 MB host-to-device copy
+// the other slots have queued: the entry count that rides back with a batch (and the batch's `done` event behind it)
+// arrived seven copies late, and the line index count of a FASTQ chunk, which the host waits for, likewise.
+__global__ void k_peek(const uint32_t *__restrict__ src, uint32_t *__restrict__ host_dst, uint32_t n_dwords) {
+    if (threadIdx.x < n_dwords) __hip_atomic_store(host_dst + threadIdx.x, src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_peek(hipStream_t s, const void *d_src, void *h_dst, uint32_t n_dwords) {
+    if (n_dwords == 0 || n_dwords > 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_peek, dim3(1), dim3(64), 0, s, (const uint32_t *)d_src, (uint32_t *)h_dst, n_dwords);
+    return hipGetLastError();
+}
+
 hipError_t launch_clear(hipStream_t s, const ClearRegions &cr) {
     for (int q = 0; q < 4; ++q)
         if (((uintptr_t)cr.p[q] & 15u) || (cr.bytes[q] & 3u)) return hipErrorInvalidValue;
