@@ -196,8 +196,8 @@ def end_to_end_leg(vfind_amd, gen, ads, n_reads, device, slots):
 def valu_util_from_profiles():
     """per-kernel VALU utilisation from the SQ counter pass committed under profiles/ (scripts/pmc_sq.sh)"""
     try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sq.json")))
-        return {"source": "profiles/r02_pmc_sq.json", "definition": j.get("definition"),
+        j = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_sq.json")))
+        return {"source": "profiles/r03_pmc_sq.json", "definition": j.get("definition"),
                 "kernels": {k: v.get("valu_util") for k, v in j.get("kernels", {}).items()}}
     except Exception:
         return None
@@ -540,7 +540,7 @@ def main():
         # rocprofv3 --pmc runs of this same workload, gfx950 FETCH_SIZE correction applied there)
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")))["kernels"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_hbm.json")))["kernels"]
             prefix = {"scan": "vf::k_scan<10", "finish": "vf::k_finish<10"}.get(dom)
             if prefix and L == 150 and n == 10_000_000:
                 traffic = next((v.get("traffic") for k, v in pmc.items() if k.startswith(prefix)), None)

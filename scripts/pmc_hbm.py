@@ -1,4 +1,4 @@
-"""profiles/r02_pmc_hbm.json from two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE) of
+"""profiles/rNN_pmc_hbm.json from two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE) of
 `VFIND_RES_LANES=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity`.
 usage: pmc_hbm.py fetch_counter_collection.csv write_counter_collection.csv out.json [n_reads row_bytes]"""
 import csv, json, re, sys, collections
@@ -35,7 +35,10 @@ for k in sorted(set(fetch) | set(write)):
         stream = n * (row_b + 4)                       # rows are fetched unconditionally, one 4-byte span per read
         e["traffic"] = int(f + stream / 2 + w)
         e["note"] = ("row + span stream (%d MB real, reported as half) + table-line fetches as reported + WRITE "
-                     "(slot stores, CAS and evicted count lines)" % (stream // 1_000_000))
+                     "(slot stores, CAS, the count log; no count line is touched since round 3)" % (stream // 1_000_000))
+    elif "k_log" in k:
+        e["traffic"] = int(f + w)
+        e["note"] = "the count log applied: entries read (4- and 8-byte gathers, taken as reported) + WRITE (grouped entries / count adds)"
     out["kernels"][k] = e
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))

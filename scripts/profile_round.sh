@@ -1,7 +1,7 @@
 # the round's profile set: scripts/profile_round.sh r02  ->  gpurun_out/<tag>_* (copy the summaries into profiles/)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-tag=${1:-r02}
+tag=${1:-r03}
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_trace -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $R/gpurun_out/${tag}_trace.log 2>&1
 f=$(find $R/gpurun_out/${tag}_trace -name "*kernel_trace.csv" | head -1)
 k=$(find $R/gpurun_out/${tag}_trace -name "*kernel_stats.csv" | head -1)

@@ -1970,7 +1970,11 @@ constexpr uint64_t kFastInsertFromTrip = VF_FAST_INSERT_FROM;   // first trip of
 #endif
 // (register caps through amdgpu_waves_per_eu were tried: 96 registers -> 32 bytes of scratch, two of its reloads on the path of
 // every trip: k_finish +15 %, k_scan beside it -8 % with its third wave per SIMD, the step +2 %; 80 registers -> +20 %)
+#ifndef VF_FINISH_WAVES
 #define VF_FINISH_ATTR __launch_bounds__(kBlock)
+#else
+#define VF_FINISH_ATTR __launch_bounds__(kBlock, VF_FINISH_WAVES)      // A/B: register cap through the minimum waves per SIMD
+#endif
 #ifdef VF_FINISH_ABLATION
 // diagnosis build: per wave of k_finish, 10 ns ticks (s_memrealtime): [0] start, [1..8] after trip 0,1,2,4,8,16,32,last,
 // [9] end, [10] insert-queue batches run, [11] ticks spent in them
