@@ -4,6 +4,8 @@
 #include "../../include/vfind_hip.h"
 #include "../../vfind_amd/csrc/vf_internal.h"
 
+#include <cstring>
+#include <cstdlib>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -40,6 +42,8 @@ void vf_internal_set_async_error(vf_ctx *, int rc, const std::string &msg) {
 uint32_t vf_internal_threads(const vf_ctx *c) { return c->threads; }
 int vf_internal_fail(int code, const std::string &msg) { t_err = msg; return code; }
 std::string vf_internal_last_error() { return t_err; }
+int vf_internal_fail_noexcept(int code, const char *msg) noexcept { try { t_err = msg; } catch (...) { } return code; }
+bool vf_internal_test_throw(const char *where) { const char *e = getenv("VFIND_TEST_THROW"); return e && strcmp(e, where) == 0; }
 extern "C" int vf_sync(vf_ctx *) {
     std::lock_guard<std::mutex> g(g_mu);
     if (g_rc) { t_err = g_msg; return g_rc; }

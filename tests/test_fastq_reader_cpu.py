@@ -188,3 +188,18 @@ def test_reader_members_decoded_by_all_threads(harness, tmp_path):
         for nt in (3, 8):
             r = _run(harness, p, nt, env=env)
             assert r["rc"] == 3 and "gzip" in r["error"], (name, nt, r)
+
+
+def test_reader_worker_exception_fails_the_run_not_the_process(harness, tmp_path):
+    """an exception on a worker thread of the reader (std::bad_alloc from a buffer, anything from below) used to be
+    std::terminate for the host process; it now fails vf_run_fastq with a message, the other workers are stopped and joined
+    (VFIND_TEST_THROW=fastq_worker makes the frame + pack workers throw), and a run without the hook is untouched"""
+    reads = synth.make_reads(9, 20000, AD20, L=150)
+    p = str(tmp_path / "m.gz")
+    synth.write_fastq_gz(p, reads, members=7)
+    for nt in (1, 3, 8):
+        out = subprocess.run([harness, p, str(nt)], capture_output=True, text=True, timeout=120, env=dict(os.environ, VFIND_TEST_THROW="fastq_worker"))
+        assert out.returncode == 0, (nt, out.returncode, out.stderr[-500:])          # the process lived to print its line
+        got = json.loads(out.stdout.strip().splitlines()[-1])
+        assert got["rc"] != 0 and "worker thread" in got["error"], got
+    assert _run(harness, p, 3) == _expect(reads)
