@@ -1394,6 +1394,7 @@ constexpr int kInlineDwords = 14;        // key dwords held inside the slot
 
 // key held in registers (static indexing)
 template <int ND> struct RegKey {
+    static constexpr uint32_t kMaxDwords = (uint32_t)ND;      // (a key held in ND registers cannot be longer: the LONG-key paths compile out)
     const uint32_t (&k)[ND];
     template <class F> __device__ __forceinline__ void each(uint32_t nd, F f) const {
 #pragma unroll
@@ -1407,6 +1408,7 @@ template <int ND> struct RegKey {
 };
 // key held in memory, element d at p[d*stride]
 struct MemKey {
+    static constexpr uint32_t kMaxDwords = 0xFFFFFFFFu;
     const uint32_t *p;
     uint64_t stride;
     template <class F> __device__ __forceinline__ void each(uint32_t nd, F f) const {
@@ -1543,7 +1545,7 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
     hash_init(h, meta);
     key.each(nd, [&](uint32_t, uint32_t v) { hash_step(h, v); });
     hash_fin(h);
-    const bool is_long = nd > (uint32_t)kInlineDwords;
+    const bool is_long = K::kMaxDwords > (uint32_t)kInlineDwords && nd > (uint32_t)kInlineDwords;
     const uint64_t w0mine = (uint64_t)h.h2 | ((uint64_t)meta << 32) | (is_long ? kW0Long : 0ull);
     const uint64_t w0pub = w0mine | (one ? kW0One : 0ull);                // what this lane writes if it inserts
     // Letter keys (kind 0) validate themselves: every dword of a written key is non-zero, so a slot can
@@ -1961,6 +1963,9 @@ __device__ __forceinline__ void slot_load2(const uint4 *p, const uint4 *q, uint4
 // lookup are queued per wave in LDS and handled 64 at a time by table_find_or_insert, so the insert
 // protocol's extra round trips are paid by full waves instead of by every wave that holds one new key.
 constexpr int kSlowCap = 192;
+#ifndef VF_FINISH_EARLY_PREFETCH
+#define VF_FINISH_EARLY_PREFETCH 1      // 0: the next row is fetched only once this trip's key is built (k_finish alone 0.412 against 0.393 ms)
+#endif
 #ifndef VF_FAST_INSERT_FROM
 #define VF_FAST_INSERT_FROM 2
 #endif
@@ -2008,7 +2013,7 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
     uint32_t *slow = s_slow[threadIdx.x / WAVE];
     uint32_t nslow = 0;                           // wave-uniform
     const uint64_t gstride = (uint64_t)gridDim.x * kBlock;
-    const uint64_t tid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;           // (32 bits per lane; read indices are formed against the wave-uniform trip base)
     const uint64_t n_trips = (n_reads + gstride * U - 1) / (gstride * U);
 
     short2 sp_next[U];
@@ -2028,32 +2033,50 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
         }
     };
 #pragma unroll
-    for (int u = 0; u < U; ++u) prefetch(u, tid + (uint64_t)u * gstride);
+    for (int u = 0; u < U; ++u) prefetch(u, (uint64_t)u * gstride + tid);
 
     VF_FIN_STAMP(0);
 #ifdef VF_FINISH_ABLATION
     uint64_t dbg_batches = 0, dbg_ticks = 0;
 #endif
+#ifdef VF_FINISH_PAD            // A/B only: VF_FINISH_PAD extra registers kept live through the trip loop (how much does the kernel's
+    uint32_t pad[VF_FINISH_PAD];   // register footprint cost the kernels that run beside it?)
+#pragma unroll
+    for (int i = 0; i < VF_FINISH_PAD; ++i) pad[i] = lane * (uint32_t)(i + 3);
+#endif
     for (uint64_t trip = 0; trip <= n_trips; ++trip) {
+#ifdef VF_FINISH_PAD
+#pragma unroll
+        for (int i = 0; i < VF_FINISH_PAD; ++i) asm volatile("" : "+v"(pad[i]));
+#endif
         const bool last = trip == n_trips;        // the extra trip only drains the slow list
         if (!last) {
             uint32_t x[U][W + 2];
             int start[U], end[U];
             bool ok[U];
-            uint64_t r[U];
+            uint32_t r[U];                        // (n_reads < 2^32: launch_finish)
             bool any_ok = false;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                r[u] = tid + (trip * U + (uint64_t)u) * gstride;
+                r[u] = (uint32_t)((trip * U + (uint64_t)u) * gstride + tid);
                 start[u] = sp_next[u].x; end[u] = sp_next[u].y;
                 ok[u] = start[u] >= 0 && end[u] >= 0 && start[u] < end[u];      // lib.rs:288
 #pragma unroll
                 for (int i = 0; i < W + 2; ++i) x[u][i] = x_next[u][i];
                 any_ok = any_ok || ok[u];
             }
+            // The next trip's row is fetched first thing (VF_FINISH_EARLY_PREFETCH=0: only once this trip's key has been built, so
+            // that the kernel holds one row at a time - no fewer registers in the end, and 5 % slower).
+#if VF_FINISH_EARLY_PREFETCH
 #pragma unroll
-            for (int u = 0; u < U; ++u) prefetch(u, r[u] + (uint64_t)U * gstride);
-            if (__any(any_ok)) {
+            for (int u = 0; u < U; ++u) prefetch(u, ((trip + 1) * U + (uint64_t)u) * gstride + tid);
+#endif
+            if (!__any(any_ok)) {
+#if !VF_FINISH_EARLY_PREFETCH
+#pragma unroll
+                for (int u = 0; u < U; ++u) prefetch(u, ((trip + 1) * U + (uint64_t)u) * gstride + tid);
+#endif
+            } else {
                 uint32_t key[U][ND];
                 uint32_t len[U];
                 bool act[U];
@@ -2066,6 +2089,10 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
                     n_ok += (uint32_t)__popcll(__ballot(ok[u]));
                     n_act += (uint32_t)__popcll(__ballot(act[u]));
                 }
+#if !VF_FINISH_EARLY_PREFETCH
+#pragma unroll
+                for (int u = 0; u < U; ++u) prefetch(u, ((trip + 1) * U + (uint64_t)u) * gstride + tid);
+#endif
                 if (lane == 0) { atomicAdd(&s_stat[0], n_ok); atomicAdd(&s_stat[1], n_act); }
                 bool found[U], cached[U], inserted[U], owner[U];
 #pragma unroll
@@ -2144,7 +2171,15 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
         const uint64_t dbg_t0 = wall_clock64();
         const uint32_t dbg_n0 = nslow;
 #endif
-        while (nslow >= (last ? 1u : (uint32_t)WAVE)) {
+        // The insert queue's claim loop is where the kernel's registers peak (a slot line, the key, the row it rebuilds the key
+        // from).  The prefetched row of the next trip is given up for its duration and fetched again behind it - CFG-explicit
+        // (if + do-while + reload), so that the row is not live across the loop; with the LONG-key paths compiled out for keys
+        // that cannot be long (RegKey::kMaxDwords) the kernel needs 91 registers instead of 100: an allocation of 96, which
+        // leaves room beside three of its waves for three k_scan waves (two before) or two k_dpall waves (one before) of the
+        // other batch lane - and the two-lane step did not move (0.859-0.880 against 0.853-0.878 ms, same box): whatever keeps
+        // the chain kernels slow beside k_finish, it is not their wave count.  A wave runs the loop on ~3 of its 51 trips.
+        if (nslow >= (last ? 1u : (uint32_t)WAVE)) {
+        do {
 #ifdef VF_FINISH_ABLATION
             ++dbg_batches;
 #endif
@@ -2165,7 +2200,11 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
             bool as;
             finish_key<W, DNA>(xs, sp.x, sp.y, oks, lut, ks, ls, as);
             bool counted;
+#ifdef VF_DIAG_NO_SLOW          // register diagnosis only (wrong results): where is the kernel's register peak?
+            const uint32_t sl = ks[0] ^ ls; counted = as;
+#else
             const uint32_t sl = table_find_or_insert(t, bt, RegKey<ND>{ks}, FK::kKind, ls, as, kNoOff, true, counted);
+#endif
             if (VF_KEYCACHE) {                  // the key's cache entry may be waiting for this slot
                 FastProbe fq;
                 fast_prepare<ND>(t, ks, FK::kKind, ls, as, fq);
@@ -2174,6 +2213,9 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
             log_one(wl, log, s_tot, sl, sl != kNoSlot && !counted && !agg_try(agg, sl));
             nslow = base;
             __builtin_amdgcn_wave_barrier();
+        } while (nslow >= (last ? 1u : (uint32_t)WAVE));
+#pragma unroll
+        for (int u = 0; u < U; ++u) prefetch(u, last ? n_reads : ((trip + 1) * U + (uint64_t)u) * gstride + tid);
         }
 #ifdef VF_FINISH_ABLATION
         if (dbg_n0 != nslow) dbg_ticks += wall_clock64() - dbg_t0;
@@ -2182,6 +2224,14 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
 #ifdef VF_FINISH_ABLATION
     VF_FIN_STAMP(9);
     if (lane == 0) { g_fin_trace[gwave][10] = dbg_batches; g_fin_trace[gwave][11] = dbg_ticks; }
+#endif
+#ifdef VF_FINISH_PAD
+    {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < VF_FINISH_PAD; ++i) acc ^= pad[i];
+        if (acc == 0xFFFFFFFFu) slow[0] = acc;           // (never true: keeps the pad alive)
+    }
 #endif
     if (lane == 0) log.n_one[gwave] = wl.n < log.cap_one ? wl.n : log.cap_one;
     __syncthreads();
