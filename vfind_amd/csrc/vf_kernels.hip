@@ -1958,6 +1958,49 @@ __device__ __forceinline__ void slot_load2(const uint4 *p, const uint4 *q, uint4
                  : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e), "=&v"(f), "=&v"(g), "=&v"(h) : "v"(p), "v"(q) : "memory");
 }
 
+// A new key's slot line written as ONE 64-byte store: the lanes that have just won a slot put their line (w0 and the 14 key
+// dwords) into a small LDS stage, and the wave writes 16 lines per store instruction, four lanes to a line, 16 bytes each -
+// a line is then one whole-line write at the memory side instead of four partial ones (the per-lane form: four
+// global_store_dwordx4 sc1 of one lane = four 16-byte writes; an insert was a line read, a CAS and four writes).  Wave-uniform
+// call; `won` lanes carry sp / w0 / kin.  stage: kLineStage lines of 16 dwords + their slot pointers, per wave.
+#ifndef VF_COOP_STORE
+#define VF_COOP_STORE 1
+#endif
+constexpr int kLineStage = 16;
+struct LineStage { u32x4 q[kLineStage][4]; unsigned long long ptr[kLineStage]; };
+__device__ __forceinline__ void coop_line_store(LineStage &st, bool won, uint4 *sp, uint64_t w0, const uint32_t (&kin)[kInlineDwords]) {
+    uint64_t m = __ballot(won);
+    const uint32_t lane = lane_id();
+    while (m) {                                                   // (wave-uniform)
+        const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const bool mine = won && ((m >> lane) & 1ull) && rank < (uint32_t)kLineStage;
+        if (mine) {
+            st.q[rank][0] = u32x4{(uint32_t)w0, (uint32_t)(w0 >> 32), kin[0], kin[1]};
+            st.q[rank][1] = u32x4{kin[2], kin[3], kin[4], kin[5]};
+            st.q[rank][2] = u32x4{kin[6], kin[7], kin[8], kin[9]};
+            st.q[rank][3] = u32x4{kin[10], kin[11], kin[12], kin[13]};
+            st.ptr[rank] = (unsigned long long)sp;
+        }
+        const uint32_t n = min((uint32_t)__popcll(m), (uint32_t)kLineStage);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t w = lane >> 2, q = lane & 3u;
+        if (w < n) {
+            const u32x4 v = *(volatile u32x4 *)&st.q[w][q];
+            uint4 *dst = reinterpret_cast<uint4 *>(*(volatile unsigned long long *)&st.ptr[w]) + q;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");
+        }
+        __builtin_amdgcn_wave_barrier();
+        // the first n set bits of m are done
+        uint64_t done = 0;
+        {
+            const bool taken = ((m >> lane) & 1ull) && rank < (uint32_t)kLineStage;
+            done = __ballot(taken);
+        }
+        m &= ~done;
+    }
+}
+
 // U reads per lane and trip (their slot lines are fetched together).  Rows and spans of the next trip are
 // prefetched before the current keys go to the table.  Reads whose key was not found by the one-shot
 // lookup are queued per wave in LDS and handled 64 at a time by table_find_or_insert, so the insert
@@ -1999,6 +2042,9 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
     __shared__ BlockTable bt;
     __shared__ uint32_t s_stat[4];                // accepted, counted, slow, (slot, count) pairs logged
     __shared__ uint32_t s_slow[kBlock / WAVE][kSlowCap];
+#if VF_COOP_STORE
+    __shared__ LineStage s_stage[kBlock / WAVE];
+#endif
     extern __shared__ uint32_t s_tot[];           // [2][kLogMaxParts] log entries per slot part (log.parts != 0 only)
     if (threadIdx.x < 64) lut[threadIdx.x] = c_codon_le[threadIdx.x];
     if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
@@ -2134,10 +2180,16 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
                                 unsigned long long old = 1ull;
                                 if (empty) old = atomicCAS(reinterpret_cast<unsigned long long *>(sp), 0ull, (unsigned long long)w0claim);
                                 const bool won = empty && old == 0ull;
+#if VF_COOP_STORE
+                                coop_line_store(s_stage[threadIdx.x / WAVE], won, sp, w0claim, fp[u].kin);
+#else
                                 if (won) {
                                     const uint32_t (&kin)[kInlineDwords] = fp[u].kin;
                                     slot_store_nowait(sp, u32x4{(uint32_t)w0claim, (uint32_t)(w0claim >> 32), kin[0], kin[1]}, u32x4{kin[2], kin[3], kin[4], kin[5]},
                                                       u32x4{kin[6], kin[7], kin[8], kin[9]}, u32x4{kin[10], kin[11], kin[12], kin[13]});
+                                }
+#endif
+                                if (won) {
                                     atomicAdd(&bt.new_entries, 1u);
                                     atomicAdd(&bt.new_key_dwords, fp[u].nd);
                                 }
