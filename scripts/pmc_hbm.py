@@ -3,7 +3,7 @@
 usage: pmc_hbm.py fetch_counter_collection.csv write_counter_collection.csv out.json [n_reads row_bytes]"""
 import csv, json, re, sys, collections
 
-def avg(path, counter, min_grid=100000):
+def avg(path, counter, min_grid=60000):      # (k_log_apply: one workgroup per 8 192 slots = 65 536 threads at 2^21 slots)
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter or int(r.get("Grid_Size", 0)) < min_grid:

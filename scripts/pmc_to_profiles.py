@@ -7,7 +7,7 @@ import json
 import re
 import sys
 
-MIN_GRID = 100000
+MIN_GRID = 60000           # (k_log_apply: 65 536 threads at 2^21 slots)
 SIMDS = 1024
 CLOCK_HZ = 2.4e9            # MI355X_MICROARCH.md: max clock; the chip holds less under load, so the utilisation is a lower bound
 ISSUE_CYCLES = 2.3          # one wave64 VALU instruction per ~2.3 cycles per SIMD at full rate
