@@ -207,7 +207,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10)     # (the first dozen steps of a process run ~1 % slower than the rest)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--adapter-len", type=int, default=20)
@@ -396,7 +396,7 @@ def main():
     # HIP events around the dominant kernel (k_finish) only inside the timed region: a bracket is two event packets
     # on the stream and bracketing all ~20 launches of a step costs 6 % of it; the other kernels' durations come
     # from a pass of the same steps right after the timed region (VFIND_BENCH_EVENTS=1: everything in the timed region)
-    ev_mode = {"0": 0, "1": 1}.get(os.environ.get("VFIND_BENCH_EVENTS", "2"), 2)
+    ev_mode = {"0": 0, "1": 1, "2": 2}.get(os.environ.get("VFIND_BENCH_EVENTS", "3"), 3)
     eng.set_profiling(ev_mode)
     barrier()
     torch.cuda.synchronize(dev)
@@ -459,7 +459,7 @@ def main():
             }
 
     # per-kernel durations of every kernel kind: the same steps again with all brackets on (not in `value`)
-    if ev_mode == 2:
+    if ev_mode in (2, 3):
         eng.reset_stats()
         eng.set_profiling(1)
         k_steps = max(min(args.steps, 10), 1)
@@ -521,12 +521,13 @@ def main():
         steps = max(args.steps, 1)
         tasks = (st["dp_prefix"] + st["dp_suffix"]) / steps / 2
         kern = {        # (event ms summed, launches, algorithmic bytes per launch, steps the sum covers)
-            "scan": ((st["ms_scan"], st["launches_scan"], n * b_alg(L), steps) if ev_mode == 2 and st["launches_scan"] else
+            "scan": ((st["ms_scan"], st["launches_scan"], n * b_alg(L), st["launches_scan"]) if ev_mode in (2, 3) and st["launches_scan"] else
                      (st_k["ms_scan"], st_k["launches_scan"], n * b_alg(L), k_steps)),                                 # timed region (mode 2)
             "filter": (st_k["ms_filter"], st_k["launches_filter"], tasks * (row_b + 10), k_steps),
             "dp_window": (st_k["ms_dp_window"], st_k["launches_dp_window"], tasks * (row_b + 14), k_steps),
             "dp_rest": (st_k["ms_dp_rest"], st_k["launches_dp_rest"], tasks * (row_b + 14), k_steps),
-            "finish": (st["ms_finish"], st["launches_finish"], n * 4 + st["accepted"] / steps * (row_b + 2), steps),   # timed region
+            # timed region; the 4th element = the steps the bracketed launches stand for (mode 3 brackets every 3rd step's)
+            "finish": (st["ms_finish"], st["launches_finish"], n * 4 + st["accepted"] / steps * (row_b + 2), max(st["launches_finish"], 1) if ev_mode == 3 else steps),
             # the batch's count log applied to the table (k_log_scatter + k_log_apply, or k_log_direct): one bracket around both
             "count_log": (st_k.get("ms_count_log", 0.0), st_k.get("launches_count_log", 0), st["counted"] / steps * 4, k_steps),
         }
@@ -559,11 +560,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(bytes_per_launch),
-                         "events": "inside the timed region" if (dom in ("finish", "scan") or ev_mode == 1) else "pass after the timed region"},
+                         "events": ("inside the timed region" + (", on every 3rd step's launch (a bracket costs the step ~2 %)" if ev_mode == 3 else "")) if (dom in ("finish", "scan") or ev_mode == 1) else "pass after the timed region",
+                         "launches_timed": int(launches)},
             "roofline_path": {"bound": "hbm", "achieved": round(path_gbps, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": round(path_gbps / HBM_PEAK_GBPS, 6), "alg_bytes_per_read": b_alg(L),
                               "kernel_ms_per_step": {k: round(v[0] / v[3], 4) for k, v in kern.items()},
-                              "kernel_ms_source": "scan, finish: HIP events inside the timed region; others: the same steps again right after it, every launch bracketed" if ev_mode == 2 else "HIP events inside the timed region"},
+                              "kernel_ms_source": ("scan, finish: HIP events inside the timed region" + (" (every 3rd step's launches)" if ev_mode == 3 else "") + "; others: the same steps again right after it, every launch bracketed") if ev_mode in (2, 3) else "HIP events inside the timed region"},
             # per kernel against the same HBM peak, and the ceilings that bind before HBM does: the
             # integer VALU if every read needed both alignments (2 L m cells at the measured 11.45 instructions per
             # cell, 256 CUs x 4 SIMDs x one wave64 instruction per ~2.3 cycles at 2.1 GHz), and PCIe for streamed input

@@ -218,8 +218,9 @@ int vf_comm_init_local(vf_ctx *ctx, int rank, vf_local_group *group);
 
 int vf_stats_get(vf_ctx *ctx, vf_stats *out);
 int vf_stats_reset(vf_ctx *ctx);
-/* on: 0 off; 1 HIP events around every kernel of the path; 2 around the two longest kernels (k_scan, k_finish) only -- each
-   bracket is two event packets on the stream, and a step has about twenty of them (measured 6 % of a step) */
+/* on: 0 off; 1 HIP events around every kernel of the path; 2 around the two longest kernels (k_scan, k_finish) only; 3 the
+   same on every third batch -- each bracket is two event packets on the stream: a step has about twenty of them with 1
+   (measured 6 % of a step), two with 2 (3-5 %), two thirds of one with 3 */
 int vf_set_profiling(vf_ctx *ctx, int on);
 
 /* Host-side helpers shared by hosts that pack themselves. */
