@@ -564,6 +564,36 @@ def test_counts_are_exact_pass_after_pass_on_two_contexts_at_once():
     assert not bad, bad[:5]
 
 
+def test_clear_by_epoch_over_forty_rounds():
+    """vf_table_clear of a letter-key table moves to the next epoch instead of zeroing the slot lines (every 15th clear zeroes):
+    stale lines must read as free slots and stale key dwords as "not written yet".  Forty rounds on one context - the same
+    slots reused round after round by other keys (a small table, few variants per round drawn from a shared pool, so stale
+    lines of the SAME key and of OTHER keys with the same home slot both occur), growth in some rounds, a merge and an export in
+    between - each round's table equals the oracle's; the same with skip_translation (packed keys: cleared by zeroing)"""
+    import torch
+    from vfind_amd import Engine
+    pools = [synth.make_reads(900 + i, 2500, AD20, L=150, n_variants=40 + 25 * (i % 7), sub=0.004, indel=0.0) for i in range(8)]
+    for kw in (dict(), dict(skip_translation=True)):
+        with Engine(AD20, table_slots=1 << 8, arena_bytes=1 << 22, batch_reads=700, queue_len=3, **kw) as e, Engine(AD20, table_slots=1 << 12, **kw) as other:
+            for rnd in range(40):
+                reads = pools[rnd % 8] + pools[(3 * rnd + 1) % 8][: 300 + 40 * (rnd % 5)]
+                e.clear()
+                e.submit(reads)
+                want = oracle.count(reads, AD20, **kw)
+                if rnd % 9 == 4:                                   # a peer's table merged into this epoch's
+                    extra = pools[(rnd + 2) % 8][:500]
+                    other.clear()
+                    other.submit(extra)
+                    n = other.export_size()
+                    buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+                    other.export_to(buf.data_ptr(), n + 64)
+                    e.merge_from(buf.data_ptr(), n)
+                    for k, v in oracle.count(extra, AD20, **kw).items():
+                        want[k] = want.get(k, 0) + v
+                assert e.finish_dict() == want, (kw, rnd)
+                assert e.stats()["table_entries"] == len(want)
+
+
 def test_count_log_both_modes_follow_the_oracle():
     """k_finish writes occurrences of known keys to the batch's count log; the log is applied by slot ranges (k_log_scatter +
     k_log_apply) or, for tables far larger than a batch, entry by entry (k_log_direct).  Both forced in turn (VFIND_COUNT_LOG,

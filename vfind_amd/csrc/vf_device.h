@@ -107,7 +107,19 @@ struct Table {
     uint64_t *counters;
     uint32_t slot_mask;
     uint64_t arena_cap;               // dwords
+    // Epoch tags (letter-key tables only; 0 = off): a slot is live only if its w0 carries the table's epoch (bits 53..56), and
+    // every key dword of a live letter key carries the epoch in the top bits of its four bytes (letters are ASCII: those bits
+    // are free) - key_tag = the pattern.  vf_table_clear then bumps the epoch instead of zeroing the slot lines (128 MB of the
+    // 151 MB a clear of a 2^21-slot table wrote; 2 GB at 2^25 slots): stale lines read as free slots, stale key dwords as
+    // "not written yet".  Every 15th clear zeroes for real (the epoch wraps).  vf_kernels.hip, "Epoch tags".
+    uint32_t epoch, key_tag;
 };
+constexpr uint32_t kTagBits = 0x80808080u;
+inline uint32_t key_tag_of(uint32_t epoch) {
+    uint32_t t = 0;
+    for (int j = 0; j < 4; ++j) if ((epoch >> j) & 1u) t |= 0x80u << (8 * j);
+    return t;
+}
 
 // ---- deferred count log (one per in-flight batch) ----------------------------------------------
 // k_finish never touches a count: an occurrence of a key that is already in the table is written down as the key's slot

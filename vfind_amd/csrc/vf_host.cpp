@@ -240,6 +240,7 @@ struct vf_ctx {
         bool valid = false;
     } spare;
     bool spare_on = true;        // VFIND_TABLE_SPARE=0: one table, cleared in place
+    bool epoch_tags = false;     // letter-key table (no skip_translation): cleared by epoch (VFIND_EPOCH_TAGS=0: always by zeroing)
     // pipeline
     std::vector<std::unique_ptr<Slot>> slots;
     std::mutex mu;
@@ -388,10 +389,19 @@ static void vf_comm_release(vf_ctx *c);
 // ------------------------------------------------------------------------------------------------
 // create / destroy
 // ------------------------------------------------------------------------------------------------
+// all_counters = the table's memory is fresh (creation, the spare's first clear): everything is zeroed.
+// Otherwise a letter-key table is cleared by moving to the next epoch (Table::epoch, vf_device.h): its slot lines - 8/9 of
+// what a clear wrote - stay as they are and read as free from now on; every 15th clear, when the epoch wraps, zeroes them.
 static int table_clear_locked(vf_ctx *c, bool all_counters = false) {
+    bool zero_slots = true;
+    if (c->epoch_tags) {
+        if (all_counters || c->tab.epoch == 0 || c->tab.epoch >= 15) c->tab.epoch = 1;
+        else { ++c->tab.epoch; zero_slots = false; }
+    } else c->tab.epoch = 0;
+    c->tab.key_tag = key_tag_of(c->tab.epoch);
     // arena top, entry count and error bits belong to the table; the read statistics do not
     ClearRegions cr;
-    cr.p[0] = c->t_slots.p;    cr.bytes[0] = c->table_slots * 64;
+    cr.p[0] = c->t_slots.p;    cr.bytes[0] = zero_slots ? c->table_slots * 64 : 0;
     cr.p[1] = c->t_counts.p;   cr.bytes[1] = c->table_slots * sizeof(unsigned long long);
     cr.p[2] = c->t_chunks.p;   cr.bytes[2] = (uint64_t)kChunkRows * kMaxGrid * sizeof(unsigned long long);
     cr.p[3] = c->t_counters.p; cr.bytes[3] = (all_counters ? (uint64_t)C_NUM : (uint64_t)kTableCounters) * sizeof(uint64_t);
@@ -452,6 +462,8 @@ static int vf_ctx_create_impl(const vf_params *p, vf_ctx **out) {
     c->T_pre = int_threshold(p->accept_prefix_alignment, p->match_score, c->pre.size());
     c->T_suf = int_threshold(p->accept_suffix_alignment, p->match_score, c->suf.size());
     c->skip_translation = p->skip_translation != 0;
+    // every key of a translating context is made of letters (ASCII): room for the epoch in each byte's top bit
+    { const char *e = getenv("VFIND_EPOCH_TAGS"); c->epoch_tags = !c->skip_translation && !(e && atoi(e) == 0); }
     c->n_threads = p->n_threads ? p->n_threads : 3;
     c->queue_len = std::min<uint32_t>(std::max<uint32_t>(p->queue_len, 1), 16);
     c->batch_reads = p->batch_reads ? p->batch_reads : (1u << 18);

@@ -1411,12 +1411,13 @@ struct MemKey {
     static constexpr uint32_t kMaxDwords = 0xFFFFFFFFu;
     const uint32_t *p;
     uint64_t stride;
+    uint32_t mask = 0xFFFFFFFFu;             // (a key read out of a tagged slot line: ~kTagBits)
     template <class F> __device__ __forceinline__ void each(uint32_t nd, F f) const {
-        for (uint32_t d = 0; d < nd; ++d) f(d, p[d * stride]);
+        for (uint32_t d = 0; d < nd; ++d) f(d, p[d * stride] & mask);
     }
     __device__ __forceinline__ void head(uint32_t nd, uint32_t (&o)[kInlineDwords]) const {
 #pragma unroll
-        for (int d = 0; d < kInlineDwords; ++d) o[d] = (uint32_t)d < nd ? p[d * stride] : 0u;
+        for (int d = 0; d < kInlineDwords; ++d) o[d] = (uint32_t)d < nd ? (p[d * stride] & mask) : 0u;
     }
 };
 
@@ -1438,6 +1439,17 @@ constexpr uint64_t kW0Ready = 1ull << 63, kW0Long = 1ull << 50, kW0Ovf = 1ull <<
 // and written back less for every new key, 1.6 M of the 8.7 M random lines of a cfg-2 step).  Set only by the claim, so
 // nothing ever has to change it; every reader of counts adds it (count_of).
 constexpr uint64_t kW0One = 1ull << 52;
+// Epoch tags (Table::epoch, vf_device.h): w0 bits 53..56.  A slot whose w0 is 0 or carries another epoch is FREE (claimed by
+// a CAS that expects exactly the stale word); a letter key's dwords carry the epoch in their bytes' top bits, so a dword left
+// over from an earlier epoch - or never written - reads as "the owner's store has not landed yet", exactly what a zero
+// dword means in an untagged table.  Untagged tables (epoch 0: packed-DNA keys have no spare bits) are cleared by zeroing.
+constexpr int kW0EpochShift = 53;
+constexpr uint64_t kW0EpochMask = 15ull << kW0EpochShift;
+__device__ __forceinline__ uint64_t w0_epoch(const Table &t) { return (uint64_t)t.epoch << kW0EpochShift; }
+__device__ __forceinline__ bool w0_free(const Table &t, uint64_t w0) { return w0 == 0ull || (w0 & kW0EpochMask) != w0_epoch(t); }
+__device__ __forceinline__ bool w0_live(const Table &t, uint64_t w0) { return (w0 & kW0Ready) && !(w0 & kW0Ovf) && (w0 & kW0EpochMask) == w0_epoch(t); }
+// has the owner's store of this key dword landed?
+__device__ __forceinline__ bool dword_written(const Table &t, uint32_t v) { return t.key_tag ? (v & kTagBits) == t.key_tag : v != 0u; }
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 
 __device__ __forceinline__ void slot_load(const uint4 *p, uint4 &a, uint4 &b, uint4 &c, uint4 &d) {
@@ -1546,7 +1558,7 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
     key.each(nd, [&](uint32_t, uint32_t v) { hash_step(h, v); });
     hash_fin(h);
     const bool is_long = K::kMaxDwords > (uint32_t)kInlineDwords && nd > (uint32_t)kInlineDwords;
-    const uint64_t w0mine = (uint64_t)h.h2 | ((uint64_t)meta << 32) | (is_long ? kW0Long : 0ull);
+    const uint64_t w0mine = (uint64_t)h.h2 | ((uint64_t)meta << 32) | (is_long ? kW0Long : 0ull) | w0_epoch(t);
     const uint64_t w0pub = w0mine | (one ? kW0One : 0ull);                // what this lane writes if it inserts
     // Letter keys (kind 0) validate themselves: every dword of a written key is non-zero, so a slot can
     // be claimed READY at once and its key stored without waiting; a reader that meets a zero dword
@@ -1556,6 +1568,10 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
     const uint64_t w0claim = selfval ? (w0pub | kW0Ready) : w0pub;
     uint32_t kin[kInlineDwords];
     key.head(nd, kin);
+    if (selfval) {                           // the slot's image of a letter key carries the epoch in every dword (padding too)
+#pragma unroll
+        for (int d = 0; d < kInlineDwords; ++d) kin[d] |= t.key_tag;
+    }
     uint32_t slot = h.h1 & t.slot_mask;
     uint32_t probes = 0;
     bool done = !active;
@@ -1580,9 +1596,10 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
             if (!claimed) {
                 slot_load(sp, l0, l1, l2, l3);
                 w0 = (uint64_t)l0.x | ((uint64_t)l0.y << 32);
-                if (w0 == 0ull) {
-                    w0 = atomicCAS(reinterpret_cast<unsigned long long *>(sp), 0ull, (unsigned long long)w0claim);
-                    claimed = w0 == 0ull;
+                if (w0_free(t, w0)) {
+                    const uint64_t seen = w0;                    // (0, or a word of an earlier epoch: the CAS expects exactly it)
+                    w0 = atomicCAS(reinterpret_cast<unsigned long long *>(sp), (unsigned long long)seen, (unsigned long long)w0claim);
+                    claimed = w0 == seen;
 #ifdef VF_INSERT_COUNTERS
                     atomicAdd((unsigned long long *)&t.counters[C_DBG2], 1ull);
                     if (claimed) atomicAdd((unsigned long long *)&t.counters[C_DBG3], 1ull);
@@ -1649,7 +1666,8 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
                         const uint32_t ln[kInlineDwords] = {l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w, l3.x, l3.y, l3.z, l3.w};
                         bool incomplete = false;
 #pragma unroll
-                        for (int d = 0; d < kInlineDwords; ++d) incomplete = incomplete || ((uint32_t)d < nd && ln[d] == 0u);
+                        // (in a tagged table the padding dwords carry the epoch too: a stale one means the line is still landing)
+                        for (int d = 0; d < kInlineDwords; ++d) incomplete = incomplete || (((uint32_t)d < nd || t.key_tag != 0u) && !dword_written(t, ln[d]));
                         if (!incomplete) advance = true;
                     }
                     else if (!confirmed && !is_long) confirmed = true;      // re-read once now that READY is known
@@ -1889,8 +1907,9 @@ __device__ __forceinline__ void finish_key(uint32_t (&x)[W + 2], int start, int 
 // dwords, then four dwords each), and nothing for a lane without a key.  A slot whose w0 matches holds a key of the
 // same length, zero padded like the lane's, so the quarters left out compare equal by construction; a quarter is
 // one request at the L2, and the lookup is bound by requests (a 12-letter peptide needs two of the four).
-__device__ __forceinline__ void slot_load_key(const uint4 *p, uint32_t nd, bool can, uint4 &a, uint4 &b, uint4 &c, uint4 &d) {
-    u32x4 va = {0u, 0u, 0u, 0u}, vb = va, vc = va, vd = va;
+__device__ __forceinline__ void slot_load_key(const uint4 *p, uint32_t nd, bool can, uint32_t tag, uint4 &a, uint4 &b, uint4 &c, uint4 &d) {
+    // (a quarter that is not fetched compares as the key's padding: zero, or the epoch pattern in a tagged table)
+    u32x4 va = {0u, 0u, tag, tag}, vb = {tag, tag, tag, tag}, vc = vb, vd = vb;
     // one asm block, predicated through exec: as separate statements the compiler copied a destination register
     // between the load and the wait (it cannot know the result is still in flight)
     const uint64_t m1 = __ballot(can), m2 = __ballot(can && nd > 2), m3 = __ballot(can && nd > 6), m4 = __ballot(can && nd > 10);
@@ -1932,9 +1951,13 @@ __device__ __forceinline__ void fast_prepare(const Table &t, const uint32_t (&ke
     p.can = act && nd <= (uint32_t)kInlineDwords;
     p.nd = nd;
     p.h1 = h.h1; p.h2 = h.h2; p.meta = meta;
-    p.w0want = (uint64_t)h.h2 | ((uint64_t)meta << 32) | kW0Ready;
+    p.w0want = (uint64_t)h.h2 | ((uint64_t)meta << 32) | kW0Ready | w0_epoch(t);
     p.slot = h.h1 & t.slot_mask;
     rk.head(nd, p.kin);
+    if (kind == kKindBytes) {                // the slot's image of a letter key: the epoch in every dword, padding too (0 in an untagged table)
+#pragma unroll
+        for (int d = 0; d < kInlineDwords; ++d) p.kin[d] |= t.key_tag;
+    }
 }
 __device__ __forceinline__ bool fast_check(const FastProbe &p, const uint4 &l0, const uint4 &l1, const uint4 &l2, const uint4 &l3) {
     const uint64_t w0 = (uint64_t)l0.x | ((uint64_t)l0.y << 32);
@@ -2165,7 +2188,7 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
                     for (int u = 0; u < U; ++u) {
                         uint4 a, b, c, d;
                         uint4 *sp = t.slots + (uint64_t)fp[u].slot * 4;
-                        slot_load_key(sp, fp[u].nd, fp[u].can, a, b, c, d);
+                        slot_load_key(sp, fp[u].nd, fp[u].can, FK::kKind == kKindBytes ? t.key_tag : 0u, a, b, c, d);
                         found[u] = fast_check(fp[u], a, b, c, d);
                         // A new key whose home slot is empty is inserted right here (letter keys: they validate themselves, so
                         // the claim is READY at once and the line is stored without a wait - table_find_or_insert's selfval
@@ -2174,12 +2197,13 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
                         // step).  Not on the first trips of a launch: there every lane that holds a hot key still finds the
                         // slot empty, and thousands of CAS on one address serialise (the queue spreads them out).
                         if constexpr (!DNA) {
-                            const bool empty = fp[u].can && (a.x | a.y) == 0u && trip >= kFastInsertFromTrip;
+                            const uint64_t w0seen = (uint64_t)a.x | ((uint64_t)a.y << 32);      // (0, or a word of an earlier epoch)
+                            const bool empty = fp[u].can && w0_free(t, w0seen) && trip >= kFastInsertFromTrip;
                             if (__any(empty)) {
                                 const uint64_t w0claim = fp[u].w0want | kW0One;
-                                unsigned long long old = 1ull;
-                                if (empty) old = atomicCAS(reinterpret_cast<unsigned long long *>(sp), 0ull, (unsigned long long)w0claim);
-                                const bool won = empty && old == 0ull;
+                                unsigned long long old = ~0ull;
+                                if (empty) old = atomicCAS(reinterpret_cast<unsigned long long *>(sp), (unsigned long long)w0seen, (unsigned long long)w0claim);
+                                const bool won = empty && old == w0seen;
 #if VF_COOP_STORE
                                 coop_line_store(s_stage[threadIdx.x / WAVE], won, sp, w0claim, fp[u].kin);
 #else
@@ -2755,7 +2779,7 @@ __global__ __launch_bounds__(kBlock) void k_owner_count(Table t, uint32_t G, uns
     for (uint64_t s = (uint64_t)blockIdx.x * kBlock + threadIdx.x; s < nslots; s += stride) {
         const uint2 h = *reinterpret_cast<const uint2 *>(t.slots + s * 4);
         const uint64_t w0 = (uint64_t)h.x | ((uint64_t)h.y << 32);
-        if ((w0 & kW0Ready) && !(w0 & kW0Ovf)) {
+        if (w0_live(t, w0)) {
             const uint32_t meta = (uint32_t)(w0 >> 32) & 0x3FFFFu;
             const uint32_t o = key_owner(w0, G);
             atomicAdd(&s_h[2 * o], 1ull);
@@ -2779,7 +2803,7 @@ __global__ __launch_bounds__(kBlock) void k_export(Table t, uint64_t *__restrict
             const uint4 *sp = t.slots + s * 4;
             l0 = sp[0];
             const uint64_t w0 = (uint64_t)l0.x | ((uint64_t)l0.y << 32);
-            live = (w0 & kW0Ready) && !(w0 & kW0Ovf) && (G == 0u || key_owner(w0, G) == owner);
+            live = w0_live(t, w0) && (G == 0u || key_owner(w0, G) == owner);
             if (live) { l1 = sp[1]; l2 = sp[2]; l3 = sp[3]; }
         }
         const uint64_t m = __ballot(live);
@@ -2813,8 +2837,9 @@ __global__ __launch_bounds__(kBlock) void k_export(Table t, uint64_t *__restrict
                 for (uint32_t d = 0; d < nd; ++d) out_arena[ko + d] = t.arena[off + d];
             } else {
                 const uint32_t kk[kInlineDwords] = {l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w, l3.x, l3.y, l3.z, l3.w};
+                const uint32_t strip = (t.key_tag && (meta >> 16) == kKindBytes) ? ~kTagBits : 0xFFFFFFFFu;      // the epoch pattern is the slot's business
 #pragma unroll
-                for (int d = 0; d < kInlineDwords; ++d) if ((uint32_t)d < nd) out_arena[ko + d] = kk[d];
+                for (int d = 0; d < kInlineDwords; ++d) if ((uint32_t)d < nd) out_arena[ko + d] = kk[d] & strip;
             }
         }
     }
@@ -2854,7 +2879,7 @@ __global__ __launch_bounds__(kBlock) void k_rehash(Table from, Table to) {
             const uint4 *sp = from.slots + s * 4;
             const uint4 l0 = sp[0];
             w0 = (uint64_t)l0.x | ((uint64_t)l0.y << 32);
-            live = (w0 & kW0Ready) && !(w0 & kW0Ovf);
+            live = w0_live(from, w0);
             if (live) {
                 cnt = count_of(from, s, w0);
                 off = (uint64_t)l0.z | ((uint64_t)l0.w << 32);
@@ -2864,7 +2889,8 @@ __global__ __launch_bounds__(kBlock) void k_rehash(Table from, Table to) {
         const uint32_t meta = (uint32_t)(w0 >> 32) & 0x3FFFFu;
         // a LONG key keeps its place in the arena (both tables share it): re-inserting it through arena_alloc doubled
         // the arena's fill with every growth and the old copies were never reclaimed
-        table_add(to, bt, MemKey{kp, 1ull}, meta >> 16, meta & 0xFFFFu, cnt, live, (live && (w0 & kW0Long)) ? off : kNoOff);
+        const uint32_t strip = (from.key_tag && !(w0 & kW0Long) && (meta >> 16) == kKindBytes) ? ~kTagBits : 0xFFFFFFFFu;
+        table_add(to, bt, MemKey{kp, 1ull, strip}, meta >> 16, meta & 0xFFFFu, cnt, live, (live && (w0 & kW0Long)) ? off : kNoOff);
     }
     __syncthreads();
     block_table_end(bt, to);
