@@ -564,7 +564,7 @@ def test_counts_are_exact_pass_after_pass_on_two_contexts_at_once():
     assert not bad, bad[:5]
 
 
-def test_clear_by_epoch_over_forty_rounds():
+def test_clear_by_epoch_over_forty_rounds(monkeypatch):
     """vf_table_clear of a letter-key table moves to the next epoch instead of zeroing the slot lines (every 15th clear zeroes):
     stale lines must read as free slots and stale key dwords as "not written yet".  Forty rounds on one context - the same
     slots reused round after round by other keys (a small table, few variants per round drawn from a shared pool, so stale
@@ -573,9 +573,10 @@ def test_clear_by_epoch_over_forty_rounds():
     import torch
     from vfind_amd import Engine
     pools = [synth.make_reads(900 + i, 2500, AD20, L=150, n_variants=40 + 25 * (i % 7), sub=0.004, indel=0.0) for i in range(8)]
-    for kw in (dict(), dict(skip_translation=True)):
+    for kw, rounds, tags in ((dict(), 40, "1"), (dict(skip_translation=True), 40, "1"), (dict(), 6, "0")):      # last: the A/B switch (zeroing everywhere)
+        monkeypatch.setenv("VFIND_EPOCH_TAGS", tags)
         with Engine(AD20, table_slots=1 << 8, arena_bytes=1 << 22, batch_reads=700, queue_len=3, **kw) as e, Engine(AD20, table_slots=1 << 12, **kw) as other:
-            for rnd in range(40):
+            for rnd in range(rounds):
                 reads = pools[rnd % 8] + pools[(3 * rnd + 1) % 8][: 300 + 40 * (rnd % 5)]
                 e.clear()
                 e.submit(reads)
