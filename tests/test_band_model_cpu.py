@@ -74,3 +74,29 @@ def test_block_model_detects_a_band_that_is_too_narrow(monkeypatch):
             ran += 1
             bad += not good
     assert bad > 0
+
+
+def test_wide_band_class_equals_full_dp(monkeypatch):
+    """class 6 of the Myers filter (vf_kernels.hip, kBandW): a task whose detected end columns form ONE cluster [jmin, jmax]
+    with jmax - jmin + 2 kerr + 1 <= 16 runs the banded DP on the diagonals [jmin - m - kerr, jmax - m + kerr], whatever its
+    edits.  Restated on the CPU against the full-matrix DP: accept / reject, score and length agree; and the model bites -
+    a band placed with kerr - 1 in the place of kerr loses alignments"""
+    rng = random.Random(20261005)
+    stats, seen = {}, 0
+    while seen < 2500:
+        good = band_model.wide_case(rng, stats)
+        if good is None:
+            continue
+        assert good
+        seen += 1
+    assert stats.get("accepted", 0) > 500 and stats.get("rejected", 0) > 500
+    real = band_model.max_unit_errors
+    monkeypatch.setattr(band_model, "max_unit_errors", lambda *a: (lambda k: k if k is None or k < 2 else k - 1)(real(*a)))
+    wrong = seen = 0
+    while seen < 1500:
+        good = band_model.wide_case(rng)
+        if good is None:
+            continue
+        seen += 1
+        wrong += not good
+    assert wrong > 0

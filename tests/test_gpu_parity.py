@@ -595,6 +595,39 @@ def test_clear_by_epoch_over_forty_rounds(monkeypatch):
                 assert e.stats()["table_entries"] == len(want)
 
 
+def test_long_keys_over_stale_lines_of_earlier_epochs():
+    """Keys longer than the 14 inline dwords keep an arena offset in their slot line.  After a clear by epoch the line a LONG
+    key claims still holds what the slot's earlier key left there - the letters of a short key, or the offset of another
+    long one - and a reader has been seen to load READY together with that stale word (round 3: the process ended with
+    HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on the load through it).  The offset word validates itself (long_word_ok):
+    30 rounds on one context, batches of 300 bp reads (keys of 8-81 letters, those above 56 LONG) and of 150 bp reads (8-31
+    letters, all inline) taking turns on the same table, two resident batches a round so that both batch lanes insert side
+    by side; every fifth round's whole table, and each of the last three, is compared with the oracle's"""
+    import torch
+    from vfind_amd import Engine
+    from benchlib import synth as vsynth
+    ads = vsynth.adapters(0x5EED0005, 20)
+    gens = [vsynth.Generator(0x5EED0005 + k, ads, read_len=L, n_variants=nv, sub_rate=0.005, indel_rate=0.0005)
+            for k, (L, nv) in enumerate(((300, 3_000_000), (150, 200_000), (300, 500_000), (150, 3_000_000)))]
+    n = 400_000
+    packed = []
+    for g in gens:
+        rows, lens = g.packed(0, n, 8)
+        packed.append((torch.from_numpy(rows).cuda(), torch.from_numpy(lens.view("int16")).cuda(), rows.shape[1]))
+    with Engine(ads, table_slots=1 << 20, arena_bytes=1 << 28) as e:
+        for rnd in range(30):
+            k = rnd % 4
+            d_rows, d_lens, W = packed[k]
+            e.clear()
+            half = n // 2                                          # two resident batches: both batch lanes insert side by side
+            e.process_device(d_rows.data_ptr(), W, d_lens.data_ptr(), half)
+            e.process_device(d_rows.data_ptr() + half * W * 4, W, d_lens.data_ptr() + half * 2, n - half)
+            if rnd % 5 == 4 or rnd >= 27:
+                data, offs = gens[k].ascii(0, n, 8)
+                assert e.finish_dict() == oracle.count((data, offs), ads, n_threads=16), rnd
+        e.sync()
+
+
 def test_count_log_both_modes_follow_the_oracle():
     """k_finish writes occurrences of known keys to the batch's count log; the log is applied by slot ranges (k_log_scatter +
     k_log_apply) or, for tables far larger than a batch, entry by entry (k_log_direct).  Both forced in turn (VFIND_COUNT_LOG,

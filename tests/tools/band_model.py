@@ -302,6 +302,69 @@ def block_case(rng, stats=None):
     return good
 
 
+# ---- the wide band (class 6 of the Myers filter): ANY single-cluster task whose cluster is narrow ------------------------
+# Every accepting alignment ends in a column of the cluster [jmin, jmax] (unit edit distance <= kerr there) and has at most
+# kerr unit edits, so all of its cells lie on the diagonals [jmin - m - kerr, jmax - m + kerr]: when those are at most
+# KBAND_W the task is a banded one, whatever its edits are (no certified column of distance <= 1 is needed: the bound is the
+# plain kerr, not the tightened one).  15 % substitutions put nearly every task here instead of into a 64-column window.
+KBAND_W = 16
+
+
+def wide_case(rng, stats=None):
+    match = rng.choice([1, 2, 3, 3, 3, 4, 5])
+    mismatch = rng.choice([-4, -3, -2, -2, -2, -1, 0])
+    gopen = rng.choice([0, 2, 3, 5, 5, 5, 8])
+    gext = rng.choice([1, 2, 2, 2, 3, 4])
+    m = rng.randint(4, 32)
+    acc = rng.choice([0.5, 0.6, 0.7, 0.75, 0.75, 0.8, 0.9])
+    T = int(acc * match * m // 1) + 1
+    ad = [rng.randrange(4) for _ in range(m)]
+    cp = list(ad)
+    for _ in range(rng.choice([0, 1, 2, 2, 3, 3, 4, 5, 6])):
+        t = rng.random()
+        p = rng.randrange(len(cp))
+        if t < 0.75:
+            cp[p] = (cp[p] + rng.randint(1, 3)) % 4
+        elif t < 0.88:
+            cp.insert(p, rng.randrange(4))
+        elif len(cp) > 2:
+            del cp[p]
+    flank = [rng.randrange(4) for _ in range(rng.choice([0, 0, 1, 2, 5, 9, 17, 40]))]
+    tail = [rng.randrange(4) for _ in range(rng.choice([0, 0, 1, 2, 3, 7, 20, 60]))]
+    read = flank + cp + tail
+    if rng.random() < 0.25:
+        read = read[rng.randint(1, 4):]
+    if rng.random() < 0.25:
+        read = read[: len(read) - rng.randint(1, 4)]
+    n = len(read)
+    if n == 0:
+        return None
+    kerr = max_unit_errors(T, m, match, mismatch, gopen, gext)
+    if kerr is None or kerr < 1 or m + kerr > 48:
+        return None
+    D = myers_last_row(ad, read)
+    det = [j for j in range(1, n + 1) if D[j] <= kerr]
+    if not det:
+        return None
+    ncl, c = clusters(det, m + kerr)
+    if ncl != 1 or (c[1] - c[0]) + 2 * kerr + 1 > KBAND_W:
+        return None
+    av = c[0] - m - kerr
+    letters = b"ACGT"
+    qb = bytes(letters[x] for x in ad)
+    rb = bytes(letters[x] for x in read)
+    fs, fl, _, _ = pyref.sg_stats_py(qb, rb, match, mismatch, gopen, gext)
+    bs, bl = banded(ad, read, av, match, mismatch, gopen, gext, KBAND=KBAND_W)
+    ok_full, ok_band = fs >= T, bs >= T
+    good = ok_full == ok_band and (not ok_full or (fs == bs and fl == bl))
+    if stats is not None:
+        stats["accepted" if ok_full else "rejected"] = stats.get("accepted" if ok_full else "rejected", 0) + 1
+    if not good:
+        print("MISMATCH (wide band)", dict(match=match, mismatch=mismatch, gopen=gopen, gext=gext, T=T, kerr=kerr, av=av, cl=c), qb, rb,
+              "full", (fs, fl), "band", (bs, bl))
+    return good
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)

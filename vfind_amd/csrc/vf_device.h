@@ -159,15 +159,17 @@ struct BatchLists {        // per in-flight batch; lists are segmented per workg
     uint32_t *winW2;                  // second window of class-3 (two-window) tasks
     uint32_t *listF;                  // filter output: tasks only the full-width DP can take
     uint32_t *listN, *winN;           // block-filter output: narrow-band tasks (+ first diagonal + kBandBias)
+    uint32_t *listB, *winB;           // Myers-filter output: wide-band tasks (class 6: one narrow cluster, any edits), same window word
     uint32_t *listR;                  // block-filter output: tasks it could not classify (the Myers filter takes them)
-    uint32_t *cntP, *cntS, *cntW[4], *cntF, *cntN, *cntR;   // kMaxGrid entries each
-    uint32_t *tot;                    // [2][8]: tasks per class (0..3, 4 = full-width rest, 5 = narrow band) of the prefix / suffix pass
+    uint32_t *cntP, *cntS, *cntW[4], *cntF, *cntN, *cntR, *cntB;   // kMaxGrid entries each
+    uint32_t *tot;                    // [2][8]: tasks per class (0..3, 4 = full-width rest, 5 = narrow band, 6 = wide band) of the prefix / suffix pass
     uint32_t grid, seg;               // from scan_geometry(n)
 };
 
 // the class lists of one filter pass as the stage functions of k_bmfilter take them
 struct ClassSet {
     uint32_t *listN, *winN;           // narrow band (block filter)
+    uint32_t *listB, *winB;           // wide band (Myers filter)
     uint32_t *listW[4], *winW[4];     // 0 banded, 1..3 windowed
     uint32_t *winW2, *listF, *listR;  // second window, full width, rest (tasks the block filter left for the Myers pass)
 };

@@ -103,7 +103,7 @@ template <typename T> struct PinBuf {
 
 struct Workspace {               // device scratch of one in-flight batch
     DevBuf<short2> spans;
-    DevBuf<uint32_t> listP, listS, listW[4], winW[4], winW2, listF, listN, winN, listR, cnt;
+    DevBuf<uint32_t> listP, listS, listW[4], winW[4], winW2, listF, listN, winN, listR, listB, winB, cnt;
     // count log of the batch's k_finish (CountLog, vf_device.h)
     DevBuf<uint32_t> log_one, log_one_by_part, log_n;     // log_n: n_one[kMaxGrid * 4], n_many[kMaxGrid], tot[2][parts], cur[2][parts]
     DevBuf<uint2> log_many, log_many_by_part;
@@ -146,13 +146,13 @@ struct Workspace {               // device scratch of one in-flight batch
         const size_t e = (size_t)g * seg;
         if ((rc = spans.ensure(n))) return rc;
         if ((rc = listP.ensure(e)) || (rc = listS.ensure(e)) || (rc = winW2.ensure(e)) || (rc = listF.ensure(e))) return rc;
-        if ((rc = listN.ensure(e)) || (rc = winN.ensure(e)) || (rc = listR.ensure(e))) return rc;
+        if ((rc = listN.ensure(e)) || (rc = winN.ensure(e)) || (rc = listR.ensure(e)) || (rc = listB.ensure(e)) || (rc = winB.ensure(e))) return rc;
         for (int q = 0; q < 4; ++q) if ((rc = listW[q].ensure(e)) || (rc = winW[q].ensure(e))) return rc;
-        return cnt.ensure(9 * kMaxGrid + 16);
+        return cnt.ensure(10 * kMaxGrid + 16);
     }
     void release() {
         spans.release(); listP.release(); listS.release(); listF.release(); winW2.release(); cnt.release();
-        listN.release(); winN.release(); listR.release();
+        listN.release(); winN.release(); listR.release(); listB.release(); winB.release();
         log_one.release(); log_one_by_part.release(); log_n.release(); log_many.release(); log_many_by_part.release();
         if (log_written) (void)hipEventDestroy(log_written);
         if (log_applied) (void)hipEventDestroy(log_applied);
@@ -784,8 +784,9 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
     bl.cntP = ws.cnt.p; bl.cntS = ws.cnt.p + kMaxGrid; bl.cntF = ws.cnt.p + 2 * kMaxGrid;
     bl.winW2 = ws.winW2.p;
     bl.listN = ws.listN.p; bl.winN = ws.winN.p; bl.listR = ws.listR.p;
-    bl.cntN = ws.cnt.p + 7 * kMaxGrid; bl.cntR = ws.cnt.p + 8 * kMaxGrid;
-    bl.tot = ws.cnt.p + 9 * kMaxGrid;
+    bl.cntN = ws.cnt.p + 7 * kMaxGrid; bl.cntR = ws.cnt.p + 8 * kMaxGrid; bl.cntB = ws.cnt.p + 9 * kMaxGrid;
+    bl.listB = ws.listB.p; bl.winB = ws.winB.p;
+    bl.tot = ws.cnt.p + 10 * kMaxGrid;
     for (int q = 0; q < 4; ++q) { bl.listW[q] = ws.listW[q].p; bl.winW[q] = ws.winW[q].p; bl.cntW[q] = ws.cnt.p + (3 + q) * kMaxGrid; }
     scan_geometry(n, &bl.grid, &bl.seg);
     // counting mode skips the suffix alignment of a read whose prefix failed (same table, less work);
@@ -1235,9 +1236,9 @@ static int vf_process_device_packed_impl(vf_ctx *c, const void *d_rows, uint32_t
     if (dbg_classes) {
         uint32_t tot[16];
         HIP_TRY(hipStreamSynchronize(L.stream));
-        HIP_TRY(hipMemcpy(tot, L.ws.cnt.p + 9 * kMaxGrid, sizeof(tot), hipMemcpyDeviceToHost));
-        fprintf(stderr, "vfind classes (narrow band, banded, window, long window, two windows, full width): prefix %u %u %u %u %u %u  suffix %u %u %u %u %u %u\n",
-                tot[5], tot[0], tot[1], tot[2], tot[3], tot[4], tot[13], tot[8], tot[9], tot[10], tot[11], tot[12]);
+        HIP_TRY(hipMemcpy(tot, L.ws.cnt.p + 10 * kMaxGrid, sizeof(tot), hipMemcpyDeviceToHost));
+        fprintf(stderr, "vfind classes (narrow band, banded, wide band, window, long window, two windows, full width): prefix %u %u %u %u %u %u %u  suffix %u %u %u %u %u %u %u\n",
+                tot[5], tot[0], tot[6], tot[1], tot[2], tot[3], tot[4], tot[13], tot[8], tot[14], tot[9], tot[10], tot[11], tot[12]);
         {
             uint64_t hits = 0;
             HIP_TRY(hipMemcpy(&hits, c->t_counters.p + C_DBG4, sizeof(hits), hipMemcpyDeviceToHost));

@@ -633,6 +633,14 @@ __device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int
 constexpr int kMaxWindow = 64;   // columns the windowed DP holds in registers (5 dwords incl. phase)
 constexpr int kBand = 10;        // diagonals the banded DP (dp_banded) computes for class 0
 constexpr int kBandN = 5;        // ... and for the narrow class of the block filter (one diagonal of block copies, +-2 unit edits)
+// ... and for class 6, the WIDE band: any task with ONE cluster of detected end columns [jmin, jmax] so narrow that
+// jmax - jmin + 2 kerr + 1 <= kBandW.  Every accepting alignment ends in a column of the cluster and has at most kerr unit
+// edits, gap bases among them, so all of its cells lie on the diagonals [jmin - m - kerr, jmax - m + kerr]:
+// the windowed DP's argument with the window cut down to its diagonals.  No certified column of distance <= 1 is needed (the
+// bound is the plain kerr), so a library with 15 % substitutions - three mismatches an adapter, DP on every read - goes
+// here instead of into a 64-column window: M x 16 cells instead of M x (m + kerr + spread) ~ M x 33.
+// tests/tools/band_model.py::wide_case restates decision and DP on the CPU against the full-matrix DP.
+constexpr int kBandW = 16;
 constexpr int kBandBias = 4096;  // class-0 window word = first diagonal + kBandBias
 
 // ------------------------------------------------------------------------------------------------
@@ -761,13 +769,20 @@ __device__ __forceinline__ int window_class(const Clusters &cl, int a1, int a2, 
     return 4;
 }
 
+// class 6 (wide band) for a single-cluster task that is not class 0: first diagonal in av
+__device__ __forceinline__ bool wide_band_class(const Clusters &cl, const DpParams &dp, int &av) {
+    if (cl.ncl != 1 || dp.kerr < 0 || dp.kerr > kBandW || (cl.jmax1 - cl.jmin1) + 2 * dp.kerr + 1 > kBandW) return false;
+    av = cl.jmin1 - (int)dp.m - dp.kerr;
+    return true;
+}
+
 // the Myers pass alone, over every task of the adapter's list (scoring schemes that give the block filter no bound, or
 // VFIND_BLOCK_FILTER=0)
 template <int W>
 __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens,
                                                    DpParams dp, short2 *__restrict__ spans, BatchLists bl,
                                                    uint64_t *__restrict__ counters) {
-    __shared__ uint32_t s_c[5];
+    __shared__ uint32_t s_c[6];
     __shared__ uint2 s_eq2[16];
     if (threadIdx.x < 16) s_eq2[threadIdx.x] = make_uint2(dp.eq_top[threadIdx.x & 3], dp.eq_top[threadIdx.x >> 2]);
     const uint32_t *list = dp.is_prefix ? bl.listP : bl.listS;
@@ -775,7 +790,7 @@ __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ 
     uint32_t stat = 0;
     for (uint32_t b = blockIdx.x; b < bl.grid; b += gridDim.x) {
         const uint32_t ntask = cnt[b];
-        if (threadIdx.x < 5) s_c[threadIdx.x] = 0u;
+        if (threadIdx.x < 6) s_c[threadIdx.x] = 0u;
         __syncthreads();
         const uint32_t n_round = (ntask + WAVE - 1) / WAVE * WAVE;
         const uint64_t seg0 = (uint64_t)b * bl.seg;
@@ -806,6 +821,12 @@ __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ 
                 const int hi = cl.jmax1 < n ? cl.jmax1 - dl : n;
                 if (hi >= lo && hi - lo + 2 * dp.kerr_lo + 1 <= kBand) { cls = 0; av = lo - (int)dp.m - dp.kerr_lo; }
             }
+            if (cls != 0 && wide_band_class(cl, dp, av)) cls = 6;
+            {
+                const bool toB = any && cls == 6;
+                const uint32_t ib = wave_append(&s_c[5], toB);
+                if (toB) { bl.listB[seg0 + ib] = r; bl.winB[seg0 + ib] = (uint32_t)(av + kBandBias); }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const bool mine = any && cls == q;
@@ -823,6 +844,7 @@ __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ 
         __syncthreads();
         if (threadIdx.x < 4) bl.cntW[threadIdx.x][b] = s_c[threadIdx.x];
         if (threadIdx.x == 4) bl.cntF[b] = s_c[4];
+        if (threadIdx.x == 6) { bl.cntB[b] = s_c[5]; if (s_c[5]) atomicAdd(&bl.tot[(dp.is_prefix ? 0u : 8u) + 6u], s_c[5]); }
         if (threadIdx.x < 5 && s_c[threadIdx.x]) atomicAdd(&bl.tot[(dp.is_prefix ? 0u : 8u) + threadIdx.x], s_c[threadIdx.x]);
         if (threadIdx.x == 5) bl.cntN[b] = 0;
         stat += ntask;
@@ -924,6 +946,12 @@ __device__ __forceinline__ void front_myers_stage(const uint32_t *__restrict__ r
             const int hi = cl.jmax1 < n ? cl.jmax1 - dl : n;
             if (hi >= lo && hi - lo + 2 * dp.kerr_lo + 1 <= kBand) { cls = 0; av = lo - (int)dp.m - dp.kerr_lo; }
         }
+        if (cls != 0 && wide_band_class(cl, dp, av)) cls = 6;
+        {
+            const bool toB = any && cls == 6;
+            const uint32_t ib = wave_append(&s_my[5], toB);
+            if (toB) { cs.listB[seg0 + ib] = r; cs.winB[seg0 + ib] = (uint32_t)(av + kBandBias); }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const bool mine = any && cls == q;
@@ -947,7 +975,7 @@ template <int W, int NB>
 __global__ __launch_bounds__(kBlock) void k_bmfilter(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, DpParams dp,
                                                      short2 *__restrict__ spans, BatchLists bl, uint64_t *__restrict__ counters) {
     __shared__ uint32_t s_bf[3];
-    __shared__ uint32_t s_my[5];
+    __shared__ uint32_t s_my[6];
     __shared__ uint2 s_eq2[16];
     __shared__ uint32_t s_row[(W + 2) * kBlock];
     if (threadIdx.x < 16) s_eq2[threadIdx.x] = make_uint2(dp.eq_top[threadIdx.x & 3], dp.eq_top[threadIdx.x >> 2]);
@@ -955,13 +983,14 @@ __global__ __launch_bounds__(kBlock) void k_bmfilter(const uint32_t *__restrict_
     const uint32_t *cnt = dp.is_prefix ? bl.cntP : bl.cntS;
     ClassSet cs;
     cs.listN = bl.listN; cs.winN = bl.winN; cs.winW2 = bl.winW2; cs.listF = bl.listF; cs.listR = bl.listR;
+    cs.listB = bl.listB; cs.winB = bl.winB;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { cs.listW[q] = bl.listW[q]; cs.winW[q] = bl.winW[q]; }
     uint32_t stat = 0;
     for (uint32_t sb = blockIdx.x; sb < bl.grid; sb += gridDim.x) {
         const uint32_t ntask = cnt[sb];
         if (threadIdx.x < 3) s_bf[threadIdx.x] = 0;
-        if (threadIdx.x < 5) s_my[threadIdx.x] = 0;
+        if (threadIdx.x < 6) s_my[threadIdx.x] = 0;
         __syncthreads();
         const uint64_t seg0 = (uint64_t)sb * bl.seg;
         if (ntask) front_bf_stage<W, NB>(rows, lens, dp, list, ntask, cs, seg0, s_bf, s_row + threadIdx.x);
@@ -977,6 +1006,8 @@ __global__ __launch_bounds__(kBlock) void k_bmfilter(const uint32_t *__restrict_
             const uint32_t tb = dp.is_prefix ? 0u : 8u;
             if (s_bf[0]) atomicAdd(&bl.tot[tb + 5u], s_bf[0]);
             for (int q = 0; q < 5; ++q) if (s_my[q]) atomicAdd(&bl.tot[tb + (uint32_t)q], s_my[q]);
+            bl.cntB[sb] = s_my[5];
+            if (s_my[5]) atomicAdd(&bl.tot[tb + 6u], s_my[5]);
         }
         stat += ntask;
         __syncthreads();
@@ -1303,21 +1334,21 @@ __global__ __launch_bounds__(kBlock) void k_dpall(const uint32_t *__restrict__ r
     // handful of tasks in a low-error library: then they run one task per WAVE (dp_coop, ~12 us a task instead of 30-70 us for
     // one lane), and a task costs a wave what 64 lanes of the other classes cost it together; as big classes (15 % adapter
     // errors: 75 000 two-window tasks) they stay one task per lane.
-    uint32_t cost[6] = {4u, 16u, 32u, 48u, 128u, 2u};
-    uint32_t nbk[6], t5[6];
+    uint32_t cost[7] = {4u, 16u, 32u, 48u, 128u, 2u, 7u};                // (index 6 = the wide band: M x kBandW cells)
+    uint32_t nbk[7], t5[7];
     uint64_t wsum = 0;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) t5[q] = __builtin_amdgcn_readfirstlane(tot[q]);
+    for (int q = 0; q < 7; ++q) t5[q] = __builtin_amdgcn_readfirstlane(tot[q]);
     const bool coop3 = t5[3] <= dp.coop_max, coop4 = t5[4] <= dp.coop_max;
     if (coop3) cost[3] = 600u;
     if (coop4) cost[4] = 600u;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) wsum += (uint64_t)t5[q] * cost[q];
+    for (int q = 0; q < 7; ++q) wsum += (uint64_t)t5[q] * cost[q];
     if (wsum == 0) return;
     const uint32_t G = gridDim.x;
     uint32_t used = 0;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
+    for (int q = 0; q < 7; ++q) {
         uint32_t b = t5[q] ? (uint32_t)((uint64_t)G * t5[q] * cost[q] / wsum) : 0u;
         // one workgroup per 256 tasks at most; classes 3 and 4 run one task per WAVE (dp_coop): one workgroup per 4 tasks
         const uint32_t per_wg = ((q == 3 && coop3) || (q == 4 && coop4)) ? (uint32_t)(kBlock / WAVE) : (uint32_t)kBlock;
@@ -1330,11 +1361,11 @@ __global__ __launch_bounds__(kBlock) void k_dpall(const uint32_t *__restrict__ r
     }
     // the minimum of one block and the single-trip raise can exceed the grid: the largest classes pay (a class keeps one block)
 #pragma unroll
-    for (int it = 0; it < 6; ++it) {
+    for (int it = 0; it < 7; ++it) {
         if (used > G) {
             int big = 0;
 #pragma unroll
-            for (int q = 1; q < 6; ++q) if (nbk[q] > nbk[big]) big = q;
+            for (int q = 1; q < 7; ++q) if (nbk[q] > nbk[big]) big = q;
             const uint32_t cut = min(used - G, nbk[big] - 1u);
             nbk[big] -= cut;
             used -= cut;
@@ -1347,6 +1378,8 @@ __global__ __launch_bounds__(kBlock) void k_dpall(const uint32_t *__restrict__ r
     b0 += nbk[5];
     if (b < b0 + nbk[0]) { VF_DP_CLASS(0); dpb_body<M, kBand>(fl, L, rows, lens, W, dp, spans, bl, bl.listW[0], bl.winW[0], bl.cntW[0], b - b0, nbk[0]); VF_DP_STAMP(3); return; }
     b0 += nbk[0];
+    if (b < b0 + nbk[6]) { VF_DP_CLASS(6); dpb_body<M, kBandW>(fl, L, rows, lens, W, dp, spans, bl, bl.listB, bl.winB, bl.cntB, b - b0, nbk[6]); VF_DP_STAMP(3); return; }
+    b0 += nbk[6];
     if (b < b0 + nbk[1]) { VF_DP_CLASS(1); dpw_body<M, false>(fl, L, rows, lens, W, dp, spans, bl, 1, b - b0, nbk[1]); VF_DP_STAMP(3); return; }
     b0 += nbk[1];
     if (b < b0 + nbk[2]) { VF_DP_CLASS(2); dpw_body<M, false>(fl, L, rows, lens, W, dp, spans, bl, 2, b - b0, nbk[2]); VF_DP_STAMP(3); return; }
@@ -1451,6 +1484,39 @@ __device__ __forceinline__ bool w0_live(const Table &t, uint64_t w0) { return (w
 // has the owner's store of this key dword landed?
 __device__ __forceinline__ bool dword_written(const Table &t, uint32_t v) { return t.key_tag ? (v & kTagBits) == t.key_tag : v != 0u; }
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+// A LONG line's key[0..1]: the key's arena offset (36 bits: the arena ends at 2^36 dwords) and, above it, 28 check bits
+// made of the line's tag and the table's epoch - never 0.  The owner stores this word, waits, and only then stores w0 | READY;
+// a reader on another XCD has all the same been seen to load READY together with what key[0..1] held BEFORE (round 3: in a
+// tagged table that is the letters of an earlier epoch's key, read as an offset of 2^62 dwords, and the load through it
+// ended the process with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION; while tables were cleared by zeroing, the stale
+// word was 0 and the compare against the key at arena[0] just failed - a duplicate entry, never noticed).  So the word
+// validates itself, like a letter key does: without its check bits, or pointing outside the arena, it has not landed yet
+// and the reader looks again.
+constexpr uint64_t kLongOffMask = (1ull << 36) - 1ull;
+__device__ __forceinline__ uint32_t long_check(const Table &t, uint32_t tag) { return (((tag >> 4) ^ t.epoch) & 0x07FFFFFFu) | 0x08000000u; }
+__device__ __forceinline__ uint64_t long_word(const Table &t, uint32_t tag, uint64_t off) { return off | ((uint64_t)long_check(t, tag) << 36); }
+__device__ __forceinline__ bool long_word_ok(const Table &t, uint32_t tag, uint64_t word, uint32_t nd) {
+    return (uint32_t)(word >> 36) == long_check(t, tag) && (word & kLongOffMask) + nd <= t.arena_cap;
+}
+// A volatile access to LDS through a GENERIC pointer compiles to a FLAT instruction (the compiler gives up on the address
+// space), and FLAT accesses to LDS travel through the vector-memory path: they are not ordered with the DS instructions of
+// the same wave.  k_finish read a line stage it had just written with ds_write through flat_load - and now and then got
+// what the LDS held before (leftovers of another kernel: a wild pointer, HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on
+// the store through it; round 3).  Every volatile LDS access goes through an explicit LDS pointer: DS
+// instructions, executed in issue order.
+#define VF_LDS(T, p) ((volatile __attribute__((address_space(3))) T *)(p))
+#ifdef VF_BOUNDS_CHECK      // diagnosis build only (make variant NAME=bc DEFS=-DVF_BOUNDS_CHECK): the first violated bound is
+// recorded in the debug counters (code, two values, workgroup) and the access is skipped
+__device__ __forceinline__ bool vf_bound(const Table &t, bool ok, uint64_t code, uint64_t v0, uint64_t v1) {
+    if (!ok && atomicCAS((unsigned long long *)&t.counters[C_DBG0], 0ull, (unsigned long long)code) == 0ull) {
+        t.counters[C_DBG1] = v0; t.counters[C_DBG2] = v1; t.counters[C_DBG3] = blockIdx.x;
+    }
+    return ok;
+}
+#define VF_BOUND(t, ok, code, v0, v1) vf_bound(t, ok, code, v0, v1)
+#else
+#define VF_BOUND(t, ok, code, v0, v1) true
+#endif
 
 __device__ __forceinline__ void slot_load(const uint4 *p, uint4 &a, uint4 &b, uint4 &c, uint4 &d) {
     asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
@@ -1505,6 +1571,7 @@ struct BlockTable {
 __device__ __forceinline__ void block_table_begin(BlockTable &bt, const Table &t) {
     if (threadIdx.x == 0) {
         bt.chunk = t.chunk_state[(uint64_t)t.chunk_row * kMaxGrid + blockIdx.x];
+        if (!VF_BOUND(t, (bt.chunk >> 32) <= t.arena_cap / kChunk && (uint32_t)bt.chunk <= (1u << 24), 1, bt.chunk, t.chunk_row)) bt.chunk = 0;
         bt.new_entries = 0;
         bt.new_key_dwords = 0;
     }
@@ -1629,9 +1696,11 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
                 } else {
                     uint64_t off = have_off;
                     const int rc = have_off != kNoOff ? (int)kAllocOk : arena_alloc(bt, t, nd, off);
-                    if (rc == kAllocOk) {
+                    if (rc == kAllocOk && !VF_BOUND(t, off + nd <= t.arena_cap, 2, off, nd)) {
+                        done = true;
+                    } else if (rc == kAllocOk) {
                         if (have_off == kNoOff) key.each(nd, [&](uint32_t d, uint32_t v) { st_agent(&t.arena[off + d], v); });
-                        st_agent(kw, (unsigned long long)off);
+                        st_agent(kw, (unsigned long long)long_word(t, h.h2, off));
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         st_agent(reinterpret_cast<unsigned long long *>(sp), (unsigned long long)(w0pub | kW0Ready));
                         atomicAdd(&bt.new_entries, 1u);
@@ -1652,15 +1721,20 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
                     done = true;
                 } else {
                     uint32_t diff = 0;
+                    bool offset_landed = true;           // (LONG lines: long_word_ok)
                     if (!is_long) {
                         diff = (l0.z ^ kin[0]) | (l0.w ^ kin[1]) | (l1.x ^ kin[2]) | (l1.y ^ kin[3]) | (l1.z ^ kin[4]) | (l1.w ^ kin[5]) |
                                (l2.x ^ kin[6]) | (l2.y ^ kin[7]) | (l2.z ^ kin[8]) | (l2.w ^ kin[9]) | (l3.x ^ kin[10]) | (l3.y ^ kin[11]) |
                                (l3.z ^ kin[12]) | (l3.w ^ kin[13]);
                     } else {
-                        const uint64_t off = (uint64_t)l0.z | ((uint64_t)l0.w << 32);
-                        key.each(nd, [&](uint32_t d, uint32_t v) { diff |= ld_agent(&t.arena[off + d]) ^ v; });
+                        const uint64_t word = (uint64_t)l0.z | ((uint64_t)l0.w << 32);
+                        const uint64_t off = word & kLongOffMask;
+                        offset_landed = long_word_ok(t, h.h2, word, nd);
+                        if (offset_landed) key.each(nd, [&](uint32_t d, uint32_t v) { diff |= ld_agent(&t.arena[off + d]) ^ v; });
                     }
-                    if (diff == 0u) { found = slot; done = true; }
+                    if (!offset_landed) {
+                        // READY seen, the offset word not yet: the same slot again next trip
+                    } else if (diff == 0u) { found = slot; done = true; }
                     else if (selfval) {
                         // a zero dword inside the key's length = the owner's stores are still in flight
                         const uint32_t ln[kInlineDwords] = {l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w, l3.x, l3.y, l3.z, l3.w};
@@ -1716,7 +1790,7 @@ __device__ __forceinline__ void agg_init(Agg &a) {
 // true = counted here
 __device__ __forceinline__ bool agg_try(Agg &a, uint32_t slot) {
     const uint32_t i = ((slot * 0x9E3779B1u) >> 16) & (uint32_t)(kAggSize - 1);
-    uint32_t cur = *(volatile uint32_t *)&a.slot[i];
+    uint32_t cur = *VF_LDS(uint32_t, &a.slot[i]);
     if (cur == kNoSlot) { cur = atomicCAS(&a.slot[i], kNoSlot, slot); if (cur == kNoSlot) cur = slot; }
     if (cur != slot) return false;
     atomicAdd(&a.cnt[i], 1u);
@@ -1780,9 +1854,9 @@ __device__ __forceinline__ void keycache_init(KeyCache &kc) {
 __device__ __forceinline__ uint32_t keycache_index(uint32_t h1) { return ((h1 * 0x9E3779B1u) >> 16) & (uint32_t)(kKeyCacheSize - 1); }
 __device__ __forceinline__ bool keycache_match(KeyCache &kc, uint32_t i, uint32_t h1, uint32_t h2, uint32_t meta, const uint32_t (&kin)[kInlineDwords]) {
     // volatile: the compiler keeps the LDS reads in program order (tags, then key words)
-    const u32x4 t0 = *(volatile u32x4 *)&kc.q[i][0];
+    const u32x4 t0 = *VF_LDS(u32x4, &kc.q[i][0]);
     if (t0.x == 0u || t0.y != h1 || t0.z != h2 || t0.w != meta) return false;
-    const u32x4 k0 = *(volatile u32x4 *)&kc.q[i][2], k1 = *(volatile u32x4 *)&kc.q[i][3];
+    const u32x4 k0 = *VF_LDS(u32x4, &kc.q[i][2]), k1 = *VF_LDS(u32x4, &kc.q[i][3]);
     const uint32_t diff = (k0.x ^ kin[0]) | (k0.y ^ kin[1]) | (k0.z ^ kin[2]) | (k0.w ^ kin[3]) |
                           (k1.x ^ kin[4]) | (k1.y ^ kin[5]) | (k1.z ^ kin[6]) | (k1.w ^ kin[7]);
     return diff == 0u;
@@ -1795,11 +1869,11 @@ __device__ __forceinline__ int keycache_probe(KeyCache &kc, uint32_t h1, uint32_
     const uint32_t i = keycache_index(h1);
     uint32_t *st = reinterpret_cast<uint32_t *>(&kc.q[i][0]);
     int role = kCacheNone;
-    if (can && *(volatile uint32_t *)st == 0u && atomicCAS(st, 0u, 1u) == 0u) {
-        *(volatile u32x4 *)&kc.q[i][2] = u32x4{kin[0], kin[1], kin[2], kin[3]};
-        *(volatile u32x4 *)&kc.q[i][3] = u32x4{kin[4], kin[5], kin[6], kin[7]};
-        *(volatile u32x4 *)&kc.q[i][1] = u32x4{kNoSlot, 0u, 0u, 0u};
-        ((volatile uint32_t *)st)[1] = h1; ((volatile uint32_t *)st)[2] = h2; ((volatile uint32_t *)st)[3] = meta;
+    if (can && *VF_LDS(uint32_t, st) == 0u && atomicCAS(st, 0u, 1u) == 0u) {
+        *VF_LDS(u32x4, &kc.q[i][2]) = u32x4{kin[0], kin[1], kin[2], kin[3]};
+        *VF_LDS(u32x4, &kc.q[i][3]) = u32x4{kin[4], kin[5], kin[6], kin[7]};
+        *VF_LDS(u32x4, &kc.q[i][1]) = u32x4{kNoSlot, 0u, 0u, 0u};
+        VF_LDS(uint32_t, st)[1] = h1; VF_LDS(uint32_t, st)[2] = h2; VF_LDS(uint32_t, st)[3] = meta;
         role = kCacheOwner;
     }
     // (the lanes of this wave that lost the claim to a lane with the same key find the key written: same instruction
@@ -1816,9 +1890,9 @@ __device__ __forceinline__ int keycache_probe(KeyCache &kc, uint32_t h1, uint32_
 __device__ __forceinline__ void keycache_publish(KeyCache &kc, uint32_t h1, uint32_t h2, uint32_t meta, const uint32_t (&kin)[kInlineDwords], uint32_t slot, bool can) {
     if (!can || slot == kNoSlot) return;
     const uint32_t i = keycache_index(h1);
-    volatile uint32_t *st = reinterpret_cast<volatile uint32_t *>(&kc.q[i][0]);
+    volatile __attribute__((address_space(3))) uint32_t *st = VF_LDS(uint32_t, &kc.q[i][0]);
     if (st[0] != 1u || !keycache_match(kc, i, h1, h2, meta, kin)) return;
-    reinterpret_cast<volatile uint32_t *>(&kc.q[i][1])[0] = slot;
+    VF_LDS(uint32_t, &kc.q[i][1])[0] = slot;
     st[0] = 2u;
 }
 // after the workgroup's last table access.  An entry with occurrences but no slot means its owner's insert failed: the
@@ -1826,7 +1900,7 @@ __device__ __forceinline__ void keycache_publish(KeyCache &kc, uint32_t h1, uint
 __device__ __forceinline__ void keycache_flush(KeyCache &kc, const Table &t, const CountLog &log, uint32_t *s_tot, uint32_t *s_nmany) {
     for (int i = threadIdx.x; i < kKeyCacheSize; i += kBlock) {
         const u32x4 t0 = kc.q[i][0], t1 = kc.q[i][1];
-        if (t0.x == 2u && t1.y) log_many(log, s_tot, s_nmany, t1.x, t1.y);
+        if (t0.x == 2u && t1.y && VF_BOUND(t, t1.x <= t.slot_mask, 8, t1.x, t1.y)) log_many(log, s_tot, s_nmany, t1.x, t1.y);
         else if (t0.x == 1u && t1.y) atomicOr((unsigned long long *)&t.counters[C_ERROR], 16ull);
     }
 }
@@ -2009,8 +2083,8 @@ __device__ __forceinline__ void coop_line_store(LineStage &st, bool won, uint4 *
         __builtin_amdgcn_wave_barrier();
         const uint32_t w = lane >> 2, q = lane & 3u;
         if (w < n) {
-            const u32x4 v = *(volatile u32x4 *)&st.q[w][q];
-            uint4 *dst = reinterpret_cast<uint4 *>(*(volatile unsigned long long *)&st.ptr[w]) + q;
+            const u32x4 v = *VF_LDS(u32x4, &st.q[w][q]);
+            uint4 *dst = reinterpret_cast<uint4 *>(*VF_LDS(unsigned long long, &st.ptr[w])) + q;
             asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");
         }
         __builtin_amdgcn_wave_barrier();
@@ -2225,12 +2299,12 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     bool to_log = false;
-                    if (found[u] && DBG != 3 && DBG != 4) to_log = !agg_try(agg, fp[u].slot);
+                    if (found[u] && DBG != 3 && DBG != 4 && VF_BOUND(t, fp[u].slot <= t.slot_mask, 4, fp[u].slot, 0)) to_log = !agg_try(agg, fp[u].slot);
                     if (VF_KEYCACHE && owner[u] && (found[u] || inserted[u])) keycache_publish(kc, fp[u].h1, fp[u].h2, fp[u].meta, fp[u].kin, fp[u].slot, true);
                     log_one(wl, log, s_tot, fp[u].slot, to_log);
                     const bool miss = act[u] && !found[u] && !cached[u] && !inserted[u];
                     const uint64_t m = __ballot(miss);
-                    if (miss) slow[nslow + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r[u];
+                    if (miss && VF_BOUND(t, nslow + (uint32_t)WAVE <= (uint32_t)kSlowCap, 6, nslow, trip)) slow[nslow + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r[u];
                     nslow += (uint32_t)__popcll(m);
                     if (m && lane == 0) atomicAdd(&s_stat[2], (uint32_t)__popcll(m));
                     // capacity: < 64 queued before a trip, at most 64 more per read of the trip
@@ -2262,10 +2336,10 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
             const uint32_t cnt = nslow < (uint32_t)WAVE ? nslow : (uint32_t)WAVE;
             const uint32_t base = nslow - cnt;
             const bool mine = lane < cnt;
-            const uint64_t rr = mine ? (uint64_t)((volatile uint32_t *)slow)[base + lane] : 0ull;
+            const uint64_t rr = mine ? (uint64_t)VF_LDS(uint32_t, slow)[base + lane] : 0ull;
             uint32_t xs[W + 2];
             short2 sp = make_short2(kNone, kNone);
-            if (mine) { sp = spans[rr]; load_row<W>(rows, rr, xs); }
+            if (mine && VF_BOUND(t, rr < n_reads, 7, rr, base)) { sp = spans[rr]; load_row<W>(rows, rr, xs); }
             else {
 #pragma unroll
                 for (int i = 0; i < W + 2; ++i) xs[i] = 0;
@@ -2286,7 +2360,7 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
                 fast_prepare<ND>(t, ks, FK::kKind, ls, as, fq);
                 keycache_publish(kc, fq.h1, fq.h2, fq.meta, fq.kin, sl, fq.can && fq.nd <= 8u);
             }
-            log_one(wl, log, s_tot, sl, sl != kNoSlot && !counted && !agg_try(agg, sl));
+            log_one(wl, log, s_tot, sl, sl != kNoSlot && VF_BOUND(t, sl <= t.slot_mask, 5, sl, ls) && !counted && !agg_try(agg, sl));
             nslow = base;
             __builtin_amdgcn_wave_barrier();
         } while (nslow >= (last ? 1u : (uint32_t)WAVE));
@@ -2833,7 +2907,7 @@ __global__ __launch_bounds__(kBlock) void k_export(Table t, uint64_t *__restrict
             out_refs[e] = (ko << 24) | kRefValid | (uint64_t)meta;
             out_counts[e] = count_of(t, s, w0);
             if (w0 & kW0Long) {
-                const uint64_t off = (uint64_t)l0.z | ((uint64_t)l0.w << 32);
+                const uint64_t off = ((uint64_t)l0.z | ((uint64_t)l0.w << 32)) & kLongOffMask;
                 for (uint32_t d = 0; d < nd; ++d) out_arena[ko + d] = t.arena[off + d];
             } else {
                 const uint32_t kk[kInlineDwords] = {l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w, l3.x, l3.y, l3.z, l3.w};
@@ -2882,7 +2956,7 @@ __global__ __launch_bounds__(kBlock) void k_rehash(Table from, Table to) {
             live = w0_live(from, w0);
             if (live) {
                 cnt = count_of(from, s, w0);
-                off = (uint64_t)l0.z | ((uint64_t)l0.w << 32);
+                off = ((uint64_t)l0.z | ((uint64_t)l0.w << 32)) & kLongOffMask;      // (an inline line's `off` is not used)
                 kp = (w0 & kW0Long) ? from.arena + off : reinterpret_cast<const uint32_t *>(sp) + 2;
             }
         }
