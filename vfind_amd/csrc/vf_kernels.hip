@@ -640,7 +640,10 @@ constexpr int kBandN = 5;        // ... and for the narrow class of the block fi
 // bound is the plain kerr), so a library with 15 % substitutions - three mismatches an adapter, DP on every read - goes
 // here instead of into a 64-column window: M x 16 cells instead of M x (m + kerr + spread) ~ M x 33.
 // tests/tools/band_model.py::wide_case restates decision and DP on the CPU against the full-matrix DP.
-constexpr int kBandW = 16;
+#ifndef VF_BAND_W
+#define VF_BAND_W 16          // (A/B: make variant NAME=bw20 DEFS=-DVF_BAND_W=20)
+#endif
+constexpr int kBandW = VF_BAND_W;
 constexpr int kBandBias = 4096;  // class-0 window word = first diagonal + kBandBias
 
 // ------------------------------------------------------------------------------------------------
@@ -1334,7 +1337,7 @@ __global__ __launch_bounds__(kBlock) void k_dpall(const uint32_t *__restrict__ r
     // handful of tasks in a low-error library: then they run one task per WAVE (dp_coop, ~12 us a task instead of 30-70 us for
     // one lane), and a task costs a wave what 64 lanes of the other classes cost it together; as big classes (15 % adapter
     // errors: 75 000 two-window tasks) they stay one task per lane.
-    uint32_t cost[7] = {4u, 16u, 32u, 48u, 128u, 2u, 7u};                // (index 6 = the wide band: M x kBandW cells)
+    uint32_t cost[7] = {4u, 16u, 32u, 48u, 128u, 2u, (uint32_t)(kBandW * 7 / 16)};                // (index 6 = the wide band: M x kBandW cells)
     uint32_t nbk[7], t5[7];
     uint64_t wsum = 0;
 #pragma unroll
