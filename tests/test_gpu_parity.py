@@ -626,6 +626,15 @@ def test_long_keys_over_stale_lines_of_earlier_epochs():
                 data, offs = gens[k].ascii(0, n, 8)
                 assert e.finish_dict() == oracle.count((data, offs), ads, n_threads=16), rnd
         e.sync()
+    # the same keys through the streaming path into a table that starts at 4 096 slots: growth re-inserts LONG lines (k_rehash
+    # reads the offset word, table_find_or_insert writes it again), epoch after epoch
+    with Engine(ads, table_slots=1 << 12, arena_bytes=1 << 20, batch_reads=20_000, queue_len=3) as e:
+        for rnd in range(6):
+            g = gens[(2 * rnd) % 4]                                 # 300 bp batches only
+            data, offs = g.ascii(rnd * 1000, 90_000, 8)
+            e.clear()
+            e.submit((data, offs))
+            assert e.finish_dict() == oracle.count((data, offs), ads, n_threads=16), rnd
 
 
 def test_count_log_both_modes_follow_the_oracle():
