@@ -7,9 +7,10 @@ T=$(mktemp -d)
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input=$T/fat.bin --output=$T/k.co --unbundle
 /opt/rocm/lib/llvm/bin/llvm-readelf --notes $T/k.co | awk '
 /\.name:/ {name=$2}
-/\.vgpr_count:/ {v=$2}
 /\.sgpr_count:/ {s=$2}
 /\.group_segment_fixed_size:/ {l=$2}
 /\.private_segment_fixed_size:/ {p=$2}
-/\.symbol:/ {printf "vgpr %-4s sgpr %-4s lds %-6s scratch %-4s %s\n", v, s, l, p, name}' | c++filt | sort -k9
+/\.vgpr_count:/ {printf "vgpr %-4s sgpr %-4s lds %-6s scratch %-4s %s\n", $2, s, l, p, name}' | c++filt | sort -k9
+# (.vgpr_count is the LAST field of a kernel's note: printing at .symbol, as this script did until round 3, paired every
+# kernel with its predecessor's register count)
 rm -rf $T

@@ -2326,11 +2326,11 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
 #endif
         // The insert queue's claim loop is where the kernel's registers peak (a slot line, the key, the row it rebuilds the key
         // from).  The prefetched row of the next trip is given up for its duration and fetched again behind it - CFG-explicit
-        // (if + do-while + reload), so that the row is not live across the loop; with the LONG-key paths compiled out for keys
-        // that cannot be long (RegKey::kMaxDwords) the kernel needs 91 registers instead of 100: an allocation of 96, which
-        // leaves room beside three of its waves for three k_scan waves (two before) or two k_dpall waves (one before) of the
-        // other batch lane - and the two-lane step did not move (0.859-0.880 against 0.853-0.878 ms, same box): whatever keeps
-        // the chain kernels slow beside k_finish, it is not their wave count.  A wave runs the loop on ~3 of its 51 trips.
+        // (if + do-while + reload), so that the row is not live across the loop, and the LONG-key paths are compiled out for keys
+        // that cannot be long (RegKey::kMaxDwords).  The kernel stands at 125 registers (103 without the key cache, 108 without
+        // this loop); three of its waves leave a SIMD room for one k_scan wave of the other batch lane, and that is not what keeps
+        // the chain kernels slow beside it: padded to 157 registers - no room at all - k_scan slows by 3 %, capped at 96 it
+        // gains 5 % and this kernel loses 30 % (EXPERIMENTS R3.6).  A wave runs the loop on ~3 of its 51 trips.
         if (nslow >= (last ? 1u : (uint32_t)WAVE)) {
         do {
 #ifdef VF_FINISH_ABLATION
@@ -3151,7 +3151,7 @@ hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint1
     hipError_t e = ensure_lut();
     if (e != hipSuccess) return e;
     // one read per lane and trip measured best once the kernel runs two workgroups per CU (7.44 vs 7.23 G reads/s over
-    // four interleaved runs each): the 105-VGPR variant leaves more of the register file to the other batch lane
+    // four interleaved runs each): the one-read variant needs 19 registers fewer (125 against 144)
     const bool u2 = finish_u2();
     uint32_t g_log, cap_one;
     const uint64_t need = count_log_entries(n, &g_log, &cap_one);
