@@ -150,7 +150,8 @@ struct CountLog {
     uint32_t parts, shift;            // parts == 0: direct mode
     uint32_t grid;                    // workgroups of the k_finish launch that wrote the log
 };
-uint64_t count_log_entries(uint64_t n_reads, uint32_t *grid, uint32_t *cap_one);   // geometry of launch_finish for n reads
+uint64_t count_log_entries(uint64_t n_reads, int W, bool dna, uint32_t *grid, uint32_t *cap_one);   // geometry of launch_finish for n reads
+uint64_t count_log_entries_max(uint64_t n_reads, uint32_t *grid_max);                              // ... over every row width and key kind
 
 // ---- launchers (vf_kernels.hip) ---------------------------------------------------------------
 struct BatchLists {        // per in-flight batch; lists are segmented per workgroup of k_scan
@@ -163,7 +164,7 @@ struct BatchLists {        // per in-flight batch; lists are segmented per workg
     uint32_t *listR;                  // block-filter output: tasks it could not classify (the Myers filter takes them)
     uint32_t *cntP, *cntS, *cntW[4], *cntF, *cntN, *cntR, *cntB;   // kMaxGrid entries each
     uint32_t *tot;                    // [2][8]: tasks per class (0..3, 4 = full-width rest, 5 = narrow band, 6 = wide band) of the prefix / suffix pass
-    uint32_t grid, seg;               // from scan_geometry(n)
+    uint32_t grid, seg;               // from scan_geometry(n, W)
 };
 
 // the class lists of one filter pass as the stage functions of k_bmfilter take them
@@ -174,7 +175,8 @@ struct ClassSet {
     uint32_t *winW2, *listF, *listR;  // second window, full width, rest (tasks the block filter left for the Myers pass)
 };
 
-void scan_geometry(uint64_t n, uint32_t *grid, uint32_t *seg);
+void scan_geometry(uint64_t n, int W, uint32_t *grid, uint32_t *seg);
+uint64_t scan_list_entries(uint64_t n);           // list entries a batch of n reads needs at any row width
 hipError_t launch_scan(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n,
                        const ScanParams &sp, short2 *spans, BatchLists bl);
 hipError_t launch_bmfilter(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
@@ -188,7 +190,7 @@ hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t 
 // k_finish, then the kernels that apply its count log (same n, same table, same log, same stream)
 hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n,
                          const short2 *spans, bool skip_translation, Table t, CountLog log);
-hipError_t launch_count_log(hipStream_t s, uint64_t n, Table t, CountLog log);
+hipError_t launch_count_log(hipStream_t s, int W, bool skip_translation, uint64_t n, Table t, CountLog log);
 hipError_t launch_generic(hipStream_t s, const uint8_t *bytes, const uint64_t *offs, uint64_t n,
                           const GenericParams &gp, int32_t *starts, int32_t *ends, int32_t *ws,
                           uint64_t ws_stride, uint32_t ws_rows, Table t);

@@ -115,8 +115,8 @@ struct Workspace {               // device scratch of one in-flight batch
     // main: the stream the log is applied on (it also zeroes a new totals array: k_finish adds to it)
     int ensure_log(size_t n, hipStream_t main) {
         int rc;
-        uint32_t g, cap_one;
-        const uint64_t e = count_log_entries(n, &g, &cap_one);
+        uint32_t g;
+        const uint64_t e = count_log_entries_max(n, &g);
         if ((rc = log_one.ensure(e)) || (rc = log_one_by_part.ensure(e))) return rc;
         if ((rc = log_many.ensure((size_t)g * kLogMany)) || (rc = log_many_by_part.ensure((size_t)g * kLogMany))) return rc;
         if (!log_written && hipEventCreateWithFlags(&log_written, hipEventDisableTiming) != hipSuccess) return fail(VF_EDEVICE, "hipEventCreate failed");
@@ -141,9 +141,7 @@ struct Workspace {               // device scratch of one in-flight batch
     }
     int ensure(size_t n) {
         int rc;
-        uint32_t g, seg;
-        scan_geometry(n, &g, &seg);
-        const size_t e = (size_t)g * seg;
+        const size_t e = (size_t)scan_list_entries(n);
         if ((rc = spans.ensure(n))) return rc;
         if ((rc = listP.ensure(e)) || (rc = listS.ensure(e)) || (rc = winW2.ensure(e)) || (rc = listF.ensure(e))) return rc;
         if ((rc = listN.ensure(e)) || (rc = winN.ensure(e)) || (rc = listR.ensure(e)) || (rc = listB.ensure(e)) || (rc = winB.ensure(e))) return rc;
@@ -788,7 +786,7 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
     bl.listB = ws.listB.p; bl.winB = ws.winB.p;
     bl.tot = ws.cnt.p + 10 * kMaxGrid;
     for (int q = 0; q < 4; ++q) { bl.listW[q] = ws.listW[q].p; bl.winW[q] = ws.winW[q].p; bl.cntW[q] = ws.cnt.p + (3 + q) * kMaxGrid; }
-    scan_geometry(n, &bl.grid, &bl.seg);
+    scan_geometry(n, W, &bl.grid, &bl.seg);
     // counting mode skips the suffix alignment of a read whose prefix failed (same table, less work);
     // the spans test hook keeps the two searches independent, as find_adapter_match is called (lib.rs:278-286)
     ScanParams sp = c->sp; DpParams dpP = c->dpP, dpS = c->dpS;
@@ -836,7 +834,7 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
         HIP_TRY(hipStreamWaitEvent(c->main_stream, ws.log_written, 0));
         {
             Timed t(c, c->main_stream, K_LOG);
-            HIP_TRY(launch_count_log(c->main_stream, n, tab, ws.count_log()));
+            HIP_TRY(launch_count_log(c->main_stream, W, c->skip_translation, n, tab, ws.count_log()));
             const CountLog l = ws.count_log();                          // part totals and scatter cursors: zero for the next batch
             HIP_TRY(hipMemsetAsync(l.tot, 0, 4 * (size_t)kLogMaxParts * sizeof(uint32_t), c->main_stream));
         }

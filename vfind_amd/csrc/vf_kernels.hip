@@ -2984,15 +2984,50 @@ static int grid_for(uint64_t n, int per_cu) {
     return (int)g;
 }
 
-void scan_geometry(uint64_t n, uint32_t *grid, uint32_t *seg) {
+// Workgroups of a kernel that a CU really holds (registers, LDS, wave slots): the persistent kernels below size their grids
+// by it.  A grid that asks for more per CU than fit runs its surplus workgroups as a second round on a half-empty chip -
+// with fixed per-CU counts the 300 bp instances did (k_finish<20> holds 189 registers: two workgroups a CU, asked for three;
+// k_scan<20> 132: three, asked for five).
+// VFIND_GRID_BY_OCCUPANCY: bit 0 k_scan and the filters, bit 1 k_finish, bit 2 k_dpall (A/B; default below)
+static int grid_fit_mask() {
+    static const int m = [] { const char *v = getenv("VFIND_GRID_BY_OCCUPANCY"); return v ? atoi(v) : 3; }();
+    return m;
+}
+template <class K> static int occupancy_of(K kernel, size_t dyn_lds) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, dyn_lds) != hipSuccess) { (void)hipGetLastError(); nb = 1; }
+    return nb < 1 ? 1 : nb;
+}
+static int w_index(int W) { return W == 10 ? 0 : W == 20 ? 1 : 2; }
+template <int W> static int scan_occupancy() {
+    // the list segments k_scan writes are read by one workgroup each of the filter kernels: the same count has to suit them
+    int o = occupancy_of(k_scan<W>, 0);
+    o = std::min(o, occupancy_of(k_filter<W>, 0));
+    o = std::min(o, std::min(occupancy_of(k_bmfilter<W, 2>, 0), std::min(occupancy_of(k_bmfilter<W, 3>, 0), occupancy_of(k_bmfilter<W, 4>, 0))));
+    return o;
+}
+static int scan_blocks_per_cu(int W) {
     // workgroups per CU of k_scan (and list segments, hence workgroups of k_filter): both kernels are persistent, and at
     // eight per CU they hold every wave slot while the other batch lane's k_finish and the table clear want in;
     // five measured best (10.8 against 10.5 G reads/s at eight, 10.7 at four, 10.4 at three, interleaved runs)
     static const int per_cu = [] { const char *v = getenv("VFIND_SCAN_BLOCKS_PER_CU"); const int x = v ? atoi(v) : 5; return x >= 1 && x <= 8 ? x : 5; }();
-    const uint32_t g = (uint32_t)grid_for(n, per_cu);
+    const bool fit = (grid_fit_mask() & 1) != 0;
+    static int occ[3] = {0, 0, 0};           // (benign race: every thread computes the same value)
+    int &o = occ[w_index(W)];
+    if (o == 0) o = W == 10 ? scan_occupancy<10>() : W == 20 ? scan_occupancy<20>() : scan_occupancy<40>();
+    return fit ? std::min(per_cu, o) : per_cu;
+}
+void scan_geometry(uint64_t n, int W, uint32_t *grid, uint32_t *seg) {
+    const uint32_t g = (uint32_t)grid_for(n, scan_blocks_per_cu(W));
     const uint64_t per_block = (n + (uint64_t)g * kBlock - 1) / ((uint64_t)g * kBlock) * kBlock;
     *grid = g;
     *seg = (uint32_t)per_block;
+}
+// list entries a batch of n reads needs whatever its row width
+uint64_t scan_list_entries(uint64_t n) {
+    uint64_t e = 0;
+    for (int W : {10, 20, 40}) { uint32_t g, seg; scan_geometry(n, W, &g, &seg); e = std::max<uint64_t>(e, (uint64_t)g * seg); }
+    return e;
 }
 
 static bool g_lut_ready[64];
@@ -3015,7 +3050,7 @@ hipError_t launch_scan(hipStream_t s, int W, const uint32_t *rows, const uint16_
                        short2 *spans, BatchLists bl) {
     if (n == 0) return hipSuccess;
     uint32_t g, seg;
-    scan_geometry(n, &g, &seg);
+    scan_geometry(n, W, &g, &seg);
     if (bl.grid != g || bl.seg != seg) return hipErrorInvalidValue;
     switch (W) {
     case 10: hipLaunchKernelGGL(k_scan<10>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, sp, spans, bl); break;
@@ -3031,7 +3066,13 @@ static void launch_dp_m(hipStream_t s, int which, int g, const uint32_t *rows, c
                         short2 *spans, BatchLists bl, const uint32_t *list, const uint32_t *cnt, uint32_t count_stat,
                         uint64_t *counters) {
     if (which == 0) hipLaunchKernelGGL(k_dp<M>, dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, list, cnt, count_stat, counters);
-    else hipLaunchKernelGGL(k_dpall<M>, dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, counters);
+    else {
+        // (the class split inside the kernel works for any grid: no more workgroups than the chip holds at once)
+        const bool fit = (grid_fit_mask() & 4) != 0;
+        static const int occ = occupancy_of(k_dpall<M>, 0);
+        const int ga = fit ? std::min(g, 256 * occ) : g;
+        hipLaunchKernelGGL(k_dpall<M>, dim3(ga), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, counters);
+    }
 }
 
 static hipError_t launch_dp_any(hipStream_t s, int which, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
@@ -3107,23 +3148,47 @@ hipError_t launch_bmfilter(hipStream_t s, int W, const uint32_t *rows, const uin
 // workgroups per CU of k_finish.  Three measured best next to a second batch lane (10.5 vs 10.3 at two and 10.1 G reads/s
 // at four, interleaved runs): the kernel is bound by the memory side (slot lines, CAS), more resident waves add
 // contention there and take registers from the DP waves of the other lane
-static int finish_per_cu() {
+static bool finish_u2();
+static int finish_per_cu(int W, bool dna) {
     static const int per_cu = [] { const char *v = getenv("VFIND_FINISH_BLOCKS_PER_CU"); const int x = v ? atoi(v) : 3; return x >= 1 && x <= 8 ? x : 3; }();
-    return per_cu;
+    const bool fit = (grid_fit_mask() & 2) != 0;
+    static int occ[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    int &o = occ[w_index(W)][dna ? 1 : 0];
+    if (o == 0) {
+        const size_t dyn = 2 * kLogMaxParts * sizeof(uint32_t);
+        if (W == 10) o = dna ? (finish_u2() ? occupancy_of(k_finish<10, 2, true>, dyn) : occupancy_of(k_finish<10, 1, true>, dyn))
+                             : (finish_u2() ? occupancy_of(k_finish<10, 2, false>, dyn) : occupancy_of(k_finish<10, 1, false>, dyn));
+        else if (W == 20) o = dna ? occupancy_of(k_finish<20, 1, true>, dyn) : occupancy_of(k_finish<20, 1, false>, dyn);
+        else o = dna ? occupancy_of(k_finish<40, 1, true>, dyn) : occupancy_of(k_finish<40, 1, false>, dyn);
+    }
+    return fit ? std::min(per_cu, o) : per_cu;
 }
 static bool finish_u2() {
     static const bool u2 = [] { const char *v = getenv("VFIND_FINISH_U"); return v && atoi(v) == 2; }();
     return u2;
 }
 // what a k_finish launch over n reads needs of the count log: workgroups, entries per wave segment, entries in all
-uint64_t count_log_entries(uint64_t n, uint32_t *grid, uint32_t *cap_one) {
-    const uint32_t g = (uint32_t)grid_for(n, finish_per_cu());
+uint64_t count_log_entries(uint64_t n, int W, bool dna, uint32_t *grid, uint32_t *cap_one) {
+    const uint32_t g = (uint32_t)grid_for(n, finish_per_cu(W, dna));
     const uint64_t gstride = (uint64_t)g * kBlock;
     const uint64_t per_wave = (n + gstride - 1) / gstride * WAVE;      // a wave sees this many reads (U reads a lane and trip: same total)
     const uint64_t cap = (per_wave + 2 * WAVE + 15) / 16 * 16;          // (U = 2 rounds the trips up to pairs)
     *grid = g;
     *cap_one = (uint32_t)cap;
     return cap * g * (kBlock / WAVE);
+}
+// log entries and (slot, count) blocks a batch of n reads needs whatever its row width and key kind
+uint64_t count_log_entries_max(uint64_t n, uint32_t *grid_max) {
+    uint64_t e = 0;
+    uint32_t gm = 0;
+    for (int W : {10, 20, 40})
+        for (int dna = 0; dna < 2; ++dna) {
+            uint32_t g, cap;
+            e = std::max(e, count_log_entries(n, W, dna != 0, &g, &cap));
+            gm = std::max(gm, g);
+        }
+    *grid_max = gm;
+    return e;
 }
 // slot parts of the count log for a table of `slots` slots and a batch of n reads: parts = 0 -> k_log_direct
 static void count_log_parts(uint64_t slots, uint64_t n, uint32_t *parts, uint32_t *shift) {
@@ -3154,7 +3219,7 @@ hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint1
     // four interleaved runs each): the one-read variant needs 19 registers fewer (125 against 144)
     const bool u2 = finish_u2();
     uint32_t g_log, cap_one;
-    const uint64_t need = count_log_entries(n, &g_log, &cap_one);
+    const uint64_t need = count_log_entries(n, W, skip_translation, &g_log, &cap_one);
     const int g = (int)g_log;
     if (log.cap_total < need || !log.one || !log.n_one || !log.many || !log.n_many) return hipErrorInvalidValue;
     log.cap_one = cap_one;
@@ -3191,10 +3256,10 @@ hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint1
 
 // the count log of the k_finish launch over the same n reads, applied to the table's counts (nothing in k_finish reads a
 // count, so the next batch's k_finish may run beside this)
-hipError_t launch_count_log(hipStream_t s, uint64_t n, Table t, CountLog log) {
+hipError_t launch_count_log(hipStream_t s, int W, bool skip_translation, uint64_t n, Table t, CountLog log) {
     if (n == 0) return hipSuccess;
     uint32_t g_log, cap_one;
-    (void)count_log_entries(n, &g_log, &cap_one);
+    (void)count_log_entries(n, W, skip_translation, &g_log, &cap_one);
     const int g = (int)g_log;
     log.cap_one = cap_one;
     log.grid = g_log;
