@@ -598,8 +598,10 @@ def test_clear_by_epoch_over_forty_rounds(monkeypatch):
 def test_long_keys_over_stale_lines_of_earlier_epochs():
     """Keys longer than the 14 inline dwords keep an arena offset in their slot line.  After a clear by epoch the line a LONG
     key claims still holds what the slot's earlier key left there - the letters of a short key, or the offset of another
-    long one - and a reader has been seen to load READY together with that stale word (round 3: the process ended with
-    HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on the load through it).  The offset word validates itself (long_word_ok):
+    long one.  Round 3: a lane whose claim CAS lost judged the w0 the CAS returned (the winner's, READY by then) against the
+    line image it had loaded before the CAS, followed those stale words as an arena offset, and the process ended with
+    HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.  Key words now wait for the next load (image_older) and the offset word
+    validates itself (long_word_ok):
     30 rounds on one context, batches of 300 bp reads (keys of 8-81 letters, those above 56 LONG) and of 150 bp reads (8-31
     letters, all inline) taking turns on the same table, two resident batches a round so that both batch lanes insert side
     by side; every fifth round's whole table, and each of the last three, is compared with the oracle's"""

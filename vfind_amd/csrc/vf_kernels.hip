@@ -1488,13 +1488,13 @@ __device__ __forceinline__ bool w0_live(const Table &t, uint64_t w0) { return (w
 __device__ __forceinline__ bool dword_written(const Table &t, uint32_t v) { return t.key_tag ? (v & kTagBits) == t.key_tag : v != 0u; }
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 // A LONG line's key[0..1]: the key's arena offset (36 bits: the arena ends at 2^36 dwords) and, above it, 28 check bits
-// made of the line's tag and the table's epoch - never 0.  The owner stores this word, waits, and only then stores w0 | READY;
-// a reader on another XCD has all the same been seen to load READY together with what key[0..1] held BEFORE (round 3: in a
-// tagged table that is the letters of an earlier epoch's key, read as an offset of 2^62 dwords, and the load through it
-// ended the process with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION; while tables were cleared by zeroing, the stale
-// word was 0 and the compare against the key at arena[0] just failed - a duplicate entry, never noticed).  So the word
-// validates itself, like a letter key does: without its check bits, or pointing outside the arena, it has not landed yet
-// and the reader looks again.
+// made of the line's tag and the table's epoch - never 0.  Insurance: nothing read from a slot line is used as an address
+// unless it validates itself and lies inside the arena.  (Round 3's fault was a reader that paired the READY w0 a lost CAS
+// had returned with the key words of the load BEFORE the CAS - table_find_or_insert, image_older - and followed the letters
+// an earlier epoch had left in key[0..1]; while tables were cleared by zeroing the stale word was 0, the compare against
+// the key at arena[0] failed and the reader inserted a duplicate, never noticed.  The hardware keeps its side: a writer's
+// store, s_waitcnt, flag store are seen in that order from another XCD - scripts/ubench/visibility.hip, 1.7 x 10^8 watched
+// transitions per variant, none torn.)  A reader that finds the word wanting looks again.
 constexpr uint64_t kLongOffMask = (1ull << 36) - 1ull;
 __device__ __forceinline__ uint32_t long_check(const Table &t, uint32_t tag) { return (((tag >> 4) ^ t.epoch) & 0x07FFFFFFu) | 0x08000000u; }
 __device__ __forceinline__ uint64_t long_word(const Table &t, uint32_t tag, uint64_t off) { return off | ((uint64_t)long_check(t, tag) << 36); }
@@ -1503,10 +1503,9 @@ __device__ __forceinline__ bool long_word_ok(const Table &t, uint32_t tag, uint6
 }
 // A volatile access to LDS through a GENERIC pointer compiles to a FLAT instruction (the compiler gives up on the address
 // space), and FLAT accesses to LDS travel through the vector-memory path: they are not ordered with the DS instructions of
-// the same wave.  k_finish read a line stage it had just written with ds_write through flat_load - and now and then got
-// what the LDS held before (leftovers of another kernel: a wild pointer, HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on
-// the store through it; round 3).  Every volatile LDS access goes through an explicit LDS pointer: DS
-// instructions, executed in issue order.
+// the same wave.  k_finish read a line stage it had just written with ds_write through flat_load (27 FLAT instructions in
+// the kernel until round 3) - never seen to go wrong, but a stale read there is a wild global store.  Every volatile LDS
+// access goes through an explicit LDS pointer: DS instructions, executed in issue order.
 #define VF_LDS(T, p) ((volatile __attribute__((address_space(3))) T *)(p))
 #ifdef VF_BOUNDS_CHECK      // diagnosis build only (make variant NAME=bc DEFS=-DVF_BOUNDS_CHECK): the first violated bound is
 // recorded in the debug counters (code, two values, workgroup) and the access is skipped
@@ -1663,6 +1662,11 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
             bool advance = false;
             uint4 l0 = make_uint4(0, 0, 0, 0), l1 = l0, l2 = l0, l3 = l0;
             uint64_t w0 = 0;
+            // the w0 a lost CAS returns is NEWER than the line image loaded before it: another lane may have claimed the slot,
+            // written its key and set READY in between.  Such a w0 may say "another key" (advance) or "not READY yet" (wait), but
+            // the key words that came with the earlier load must not be compared or followed under it (round 3: a LONG key's
+            // reader took the letters an earlier epoch had left in key[0..1] for an arena offset).
+            bool image_older = false;
             if (!claimed) {
                 slot_load(sp, l0, l1, l2, l3);
                 w0 = (uint64_t)l0.x | ((uint64_t)l0.y << 32);
@@ -1670,6 +1674,10 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
                     const uint64_t seen = w0;                    // (0, or a word of an earlier epoch: the CAS expects exactly it)
                     w0 = atomicCAS(reinterpret_cast<unsigned long long *>(sp), (unsigned long long)seen, (unsigned long long)w0claim);
                     claimed = w0 == seen;
+                    image_older = !claimed;
+#ifdef VF_NO_IMAGE_GUARD        // diagnosis build only (with -DVF_LONG_DIAG): round 3's behaviour, the offset check alone catches it
+                    image_older = false;
+#endif
 #ifdef VF_INSERT_COUNTERS
                     atomicAdd((unsigned long long *)&t.counters[C_DBG2], 1ull);
                     if (claimed) atomicAdd((unsigned long long *)&t.counters[C_DBG3], 1ull);
@@ -1718,8 +1726,9 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
                     }
                 }
             } else if ((w0 & ~(kW0Ready | kW0Ovf | kW0One)) == w0mine) {
-                if (!(w0 & kW0Ready)) {
-                    // claimed by another lane, key not yet published: look at the same slot again next trip
+                if (!(w0 & kW0Ready) || image_older) {
+                    // claimed by another lane, key not yet published - or published after this trip's load: look at the same
+                    // slot again next trip
                 } else if (w0 & kW0Ovf) {
                     done = true;
                 } else {
@@ -1733,6 +1742,9 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
                         const uint64_t word = (uint64_t)l0.z | ((uint64_t)l0.w << 32);
                         const uint64_t off = word & kLongOffMask;
                         offset_landed = long_word_ok(t, h.h2, word, nd);
+#ifdef VF_LONG_DIAG             // diagnosis build only: [C_DBG0] offset words that did not validate, [C_DBG1] LONG lines compared
+                        atomicAdd((unsigned long long *)&t.counters[offset_landed ? C_DBG1 : C_DBG0], 1ull);
+#endif
                         if (offset_landed) key.each(nd, [&](uint32_t d, uint32_t v) { diff |= ld_agent(&t.arena[off + d]) ^ v; });
                     }
                     if (!offset_landed) {
