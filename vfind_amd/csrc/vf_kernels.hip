@@ -2158,6 +2158,9 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
     __shared__ LineStage s_stage[kBlock / WAVE];
 #endif
     extern __shared__ uint32_t s_tot[];           // [2][kLogMaxParts] log entries per slot part (log.parts != 0 only)
+#ifdef VF_FINISH_PRIO            // A/B: the table kernel's waves issue ahead of the chain kernels' waves on a shared SIMD
+    __builtin_amdgcn_s_setprio(VF_FINISH_PRIO);
+#endif
     if (threadIdx.x < 64) lut[threadIdx.x] = c_codon_le[threadIdx.x];
     if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
     if (log.parts) for (uint32_t i = threadIdx.x; i < 2 * kLogMaxParts; i += kBlock) s_tot[i] = 0;
