@@ -210,8 +210,13 @@ __device__ __forceinline__ void exact_find2(const uint32_t (&r)[W + 2], const ui
 // Work lists are segmented per workgroup: block b appends to list[b*seg ..) through a counter in LDS
 // and publishes the count at kernel end, so no global counter is ever contended (a single global
 // append counter serialises ~10 ns per wave and dominated this kernel).
+#ifndef VF_SCAN_WAVES
+#define VF_SCAN_ATTR __launch_bounds__(kBlock)
+#else
+#define VF_SCAN_ATTR __launch_bounds__(kBlock, VF_SCAN_WAVES)      // A/B: register cap (8 -> 64 registers: two waves fit a SIMD beside three k_finish waves)
+#endif
 template <int W>
-__global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens,
+__global__ VF_SCAN_ATTR void k_scan(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens,
                                                  uint64_t n_reads, ScanParams sp, short2 *__restrict__ spans,
                                                  BatchLists bl) {
     __shared__ uint32_t s_cnt[2];
