@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VF_ABI_VERSION 3
+#define VF_ABI_VERSION 4
 
 enum {
     VF_OK = 0,
@@ -86,6 +86,22 @@ typedef struct vf_stats {
     uint64_t dbg[4];           /* diagnosis build only (insert-path batches, loop trips, CAS issued, CAS won); 0 in the product */
     double ms_count_log;       /* device time of the kernels that apply a batch's count log to the table (profiling on) */
     uint64_t launches_count_log;
+    /* ABI 4 */
+    uint64_t dup_rows;         /* rows the latest vf_finish / vf_finish_blobs folded into another row because their strings were
+                                  equal: 0 for one context's own table unless the insert protocol let a key in twice (a stale view
+                                  of a slot; summed, so the frame is right either way - but a non-zero value in a single-lane run is
+                                  a protocol bug showing); the number of keys several blobs share for vf_finish_blobs */
+    /* stages of vf_run_fastq since creation / vf_stats_reset, host steady_clock, milliseconds (lib.rs:233-234, 271-274 replaced):
+       wall = whole calls; inflate = time inside the gzip decoder summed over the inflate threads (fq_inflate_threads of them;
+       a single large member decoded by all threads counts its wall time once per thread); seq_wait = the in-order sequencer
+       waiting for decoded text (inflate-bound when large); queue_full = the sequencer waiting for a free place in the chunk
+       queue (device- or submit-bound when large); submit = inside the per-chunk submit summed over the submitting threads, of
+       which slot_wait = waiting for a free batch slot and index_wait = waiting for the chunk's line index to come back from
+       the device; drain = the final wait for the device */
+    double fq_wall_ms, fq_inflate_ms, fq_seq_wait_ms, fq_queue_full_ms, fq_submit_ms, fq_slot_wait_ms, fq_index_wait_ms, fq_drain_ms;
+    uint64_t fq_comp_bytes, fq_text_bytes, fq_inflate_threads, fq_chunks;
+    double ms_h2d, ms_frame;   /* device time of the text copies and of the line-index + frame + pack kernels (profiling on) */
+    uint64_t launches_h2d, launches_frame;
 } vf_stats;
 
 const char *vf_last_error(void);
@@ -203,7 +219,11 @@ int vf_table_partition_export(vf_ctx *ctx, uint32_t world, uint32_t owner, void 
 int vf_comm_unique_id(void *id128);
 int vf_comm_init(vf_ctx *ctx, int rank, int world, const void *id128);
 /* On a local failure of one rank (no memory for a buffer, a table that cannot grow) every rank returns an error: the ranks
- * exchange a status word before each round of transfers, nobody is left waiting for a peer that has gone. */
+ * exchange a status word before each round of transfers (its staging is allocated by vf_comm_init, so saying "I failed" cannot
+ * itself fail), nobody is left waiting for a peer that has gone.  A failure of the transport itself, or a collective that does
+ * not complete within VFIND_EXCHANGE_TIMEOUT_S seconds (default 120, 0 = wait for ever), closes an open ncclGroupStart,
+ * aborts the communicator (ncclCommAbort) and returns an error: the call cannot hang on a dead peer.  The context needs a
+ * new vf_comm_init after that. */
 int vf_table_allreduce(vf_ctx *ctx, int root);
 
 /* The same exchange between contexts of ONE process (one host thread per context, on one device or several): a group

@@ -3,7 +3,7 @@
 //! parasail aligner and the HashMap reduce are gone: they run as HIP kernels behind `vf_*`.
 use polars::prelude::*;
 use polars_arrow::ffi;
-use pyo3::exceptions::{PyOSError, PyRuntimeError, PyValueError};
+use pyo3::exceptions::{PyMemoryError, PyOSError, PyRuntimeError, PyValueError};
 use pyo3::prelude::*;
 use pyo3_polars::PyDataFrame;
 use std::ffi::{c_int, CStr, CString};
@@ -12,7 +12,8 @@ use std::fs::File;
 mod vf_abi;
 use vf_abi::*;
 
-/// VF_EINVAL -> ValueError (same text as the reference's preflight), VF_EIO -> OSError, else RuntimeError
+/// VF_EINVAL -> ValueError (same text as the reference's preflight), VF_EIO -> OSError, VF_ENOMEM -> MemoryError,
+/// else RuntimeError (the codes of include/vfind_hip.h; tests/test_abi.py keeps these arms and vfind_amd/_lib.py::check in step)
 fn check(rc: c_int) -> PyResult<()> {
     if rc == 0 {
         return Ok(());
@@ -21,6 +22,7 @@ fn check(rc: c_int) -> PyResult<()> {
     Err(match rc {
         1 => PyValueError::new_err(msg),
         2 => PyOSError::new_err(msg),
+        6 => PyMemoryError::new_err(msg),
         _ => PyRuntimeError::new_err(msg),
     })
 }

@@ -1,4 +1,4 @@
-//! `extern "C"` declarations of every entry point of include/vfind_hip.h (VF_ABI_VERSION 3), in the header's order.
+//! `extern "C"` declarations of every entry point of include/vfind_hip.h (VF_ABI_VERSION 4), in the header's order.
 //! tests/test_abi.py checks that this list and the header name the same functions.
 #![allow(dead_code)]
 use std::ffi::{c_char, c_int, c_void};
@@ -40,6 +40,11 @@ pub struct VfStats {
     pub launches_generic: u64, pub insert_path: u64, pub arena_top: u64,
     pub ms_result_build: f64, pub result_rows: u64, pub dbg: [u64; 4],
     pub ms_count_log: f64, pub launches_count_log: u64,
+    pub dup_rows: u64,
+    pub fq_wall_ms: f64, pub fq_inflate_ms: f64, pub fq_seq_wait_ms: f64, pub fq_queue_full_ms: f64, pub fq_submit_ms: f64, pub fq_slot_wait_ms: f64,
+    pub fq_index_wait_ms: f64, pub fq_drain_ms: f64,
+    pub fq_comp_bytes: u64, pub fq_text_bytes: u64, pub fq_inflate_threads: u64, pub fq_chunks: u64,
+    pub ms_h2d: f64, pub ms_frame: f64, pub launches_h2d: u64, pub launches_frame: u64,
 }
 
 extern "C" {

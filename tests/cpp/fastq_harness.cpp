@@ -31,6 +31,8 @@ int vf_internal_submit(vf_ctx *, const uint8_t *base, const ReadRef *reads, uint
     return 0;
 }
 // device framing is a GPU path; the harness exercises the host framer
+static VfFastqStats g_fq_stats;
+VfFastqStats *vf_internal_fastq_stats(vf_ctx *) { return &g_fq_stats; }
 bool vf_internal_device_framing(const vf_ctx *) { return false; }
 uint8_t *vf_internal_alloc_pinned(const vf_ctx *, size_t n) { return (uint8_t *)malloc(n); }
 void vf_internal_free_pinned(uint8_t *p) { free(p); }

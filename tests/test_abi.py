@@ -212,3 +212,37 @@ def test_rust_structs_have_the_c_layout(tmp_path):
         c = dict(lay[cname])
         assert c.pop("sizeof")[0] == total, rname
         assert list(fields.items()) == sorted(c.items(), key=lambda kv: kv[1][0]), rname
+
+
+def test_rust_check_and_python_check_map_the_same_codes():
+    """rust/src/lib.rs::check and vfind_amd/_lib.py::check turn the same VF_E* codes into the same exception families
+    (INTEGRATION.md section 2): ValueError, OSError, MemoryError, everything else a runtime error"""
+    from vfind_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "vfind_hip.h")).read()
+    codes = {name: int(v) for name, v in re.findall(r"\b(VF_E[A-Z]+)\s*=\s*(\d+)", hdr)}
+    assert codes == {"VF_EINVAL": 1, "VF_EIO": 2, "VF_EFORMAT": 3, "VF_EDEVICE": 4, "VF_ECAPACITY": 5, "VF_ENOMEM": 6}
+    rs = open(os.path.join(ROOT, "rust", "src", "lib.rs")).read()
+    body = rs[rs.index("fn check("):rs.index("struct Ctx")]
+    arms = {int(c): exc for c, exc in re.findall(r"(\d+)\s*=>\s*(Py\w+)::new_err", body)}
+    default = re.search(r"_\s*=>\s*(Py\w+)::new_err", body).group(1)
+    family = {"PyValueError": ValueError, "PyOSError": OSError, "PyMemoryError": MemoryError, "PyRuntimeError": RuntimeError}
+
+    class _L:                                    # _lib.check only asks the library for the message
+        @staticmethod
+        def vf_last_error():
+            return b"No such file or directory"
+    saved = _lib._lib
+    _lib._lib = _L
+    try:
+        for name, code in codes.items():
+            want = family[arms.get(code, default)]
+            with pytest.raises(want) as ei:
+                _lib.check(code)
+            # and nothing broader on the Python side: a code Rust sends to RuntimeError is not an OSError / ValueError there
+            if want is RuntimeError:
+                assert not isinstance(ei.value, (OSError, ValueError, MemoryError)), name
+    finally:
+        _lib._lib = saved
+    inte = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for c, exc in arms.items():
+        assert exc in inte, exc

@@ -18,5 +18,10 @@ int main(void) {
     F(vf_stats, launches_scan); F(vf_stats, launches_filter); F(vf_stats, launches_dp_window); F(vf_stats, launches_dp_rest);
     F(vf_stats, launches_finish); F(vf_stats, launches_generic); F(vf_stats, insert_path); F(vf_stats, arena_top);
     F(vf_stats, ms_result_build); F(vf_stats, result_rows); F(vf_stats, dbg); F(vf_stats, ms_count_log); F(vf_stats, launches_count_log);
+    F(vf_stats, dup_rows);
+    F(vf_stats, fq_wall_ms); F(vf_stats, fq_inflate_ms); F(vf_stats, fq_seq_wait_ms); F(vf_stats, fq_queue_full_ms); F(vf_stats, fq_submit_ms);
+    F(vf_stats, fq_slot_wait_ms); F(vf_stats, fq_index_wait_ms); F(vf_stats, fq_drain_ms);
+    F(vf_stats, fq_comp_bytes); F(vf_stats, fq_text_bytes); F(vf_stats, fq_inflate_threads); F(vf_stats, fq_chunks);
+    F(vf_stats, ms_h2d); F(vf_stats, ms_frame); F(vf_stats, launches_h2d); F(vf_stats, launches_frame);
     return 0;
 }

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libvfind_hip.so")
 
 VF_OK, VF_EINVAL, VF_EIO, VF_EFORMAT, VF_EDEVICE, VF_ECAPACITY, VF_ENOMEM = range(7)
-ABI_VERSION = 3          # VF_ABI_VERSION of include/vfind_hip.h
+ABI_VERSION = 4          # VF_ABI_VERSION of include/vfind_hip.h
 
 
 class VfParams(C.Structure):
@@ -36,7 +36,11 @@ class VfStats(C.Structure):
         (n, C.c_double) for n in ("ms_scan", "ms_filter", "ms_dp_window", "ms_dp_rest", "ms_finish", "ms_generic")] + [
         (n, C.c_uint64) for n in ("launches_scan", "launches_filter", "launches_dp_window", "launches_dp_rest", "launches_finish", "launches_generic",
                                   "insert_path", "arena_top")] + [("ms_result_build", C.c_double), ("result_rows", C.c_uint64)] + [(f"dbg{k}", C.c_uint64) for k in range(4)] + [
-        ("ms_count_log", C.c_double), ("launches_count_log", C.c_uint64)]
+        ("ms_count_log", C.c_double), ("launches_count_log", C.c_uint64), ("dup_rows", C.c_uint64)] + [
+        (n, C.c_double) for n in ("fq_wall_ms", "fq_inflate_ms", "fq_seq_wait_ms", "fq_queue_full_ms", "fq_submit_ms", "fq_slot_wait_ms", "fq_index_wait_ms",
+                                  "fq_drain_ms")] + [
+        (n, C.c_uint64) for n in ("fq_comp_bytes", "fq_text_bytes", "fq_inflate_threads", "fq_chunks")] + [
+        ("ms_h2d", C.c_double), ("ms_frame", C.c_double), ("launches_h2d", C.c_uint64), ("launches_frame", C.c_uint64)]
 
 
 # every symbol include/vfind_hip.h declares: (name, restype, argtypes)

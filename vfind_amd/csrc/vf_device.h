@@ -75,7 +75,7 @@ enum { kKindBytes = 0, kKindPacked = 1 };
 enum Counter : int {        // uint64 counters[] in device memory
     C_ARENA_TOP = 0,        // dwords of the long-key arena handed out
     C_ENTRIES = 1,
-    C_ERROR = 2,            // bit0 arena full, bit1 table full, bit2 key too long
+    C_ERROR = 2,            // bit0 arena full, bit1 table full, bit2 key too long, bit3 count log inconsistent, bit4 key cache entry without a slot, bit5 unmergeable byte key
     C_KEY_DWORDS = 3,       // total key dwords of all entries (size of an export)
     C_ACCEPTED = 4,
     C_COUNTED = 5,

@@ -51,6 +51,7 @@ namespace {
 
 constexpr uint64_t kGrid = 4ull << 20;         // compressed bytes per decode task (at least)
 constexpr size_t kPiece = 8u << 20;            // decoded text piece
+static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
 static size_t spec_cap() {                     // text a not-yet-needed task may buffer (tests shrink it)
     static const size_t v = [] { const char *e = getenv("VFIND_FASTQ_SPEC_CAP"); return e ? (size_t)strtoull(e, nullptr, 0) : (size_t)(96u << 20); }();
     return v;
@@ -153,6 +154,7 @@ struct Reader {
     bool stop = false;
     bool big_members = false;                  // few, large members: one task at a time, each member decoded by all threads
     uint32_t par_threads = 1;
+    VfFastqStats *fq = nullptr;                // stage timers of the context (vf_stats.fq_*)
 
     bool is_member_start(uint64_t off) const {
         return off + 18 <= size && file[off] == 0x1f && file[off + 1] == 0x8b && file[off + 2] == 8 && (file[off + 3] & 0xE0) == 0;
@@ -226,6 +228,7 @@ static void run_task(Reader &R, const std::shared_ptr<Task> &t) {
         io.put_piece = [&](uint8_t *b, size_t n, size_t nl) -> bool {
             std::unique_lock<std::mutex> lk(R.mu);
             Piece pc; pc.data = b; pc.size = n; pc.nl = nl;
+            R.fq->text_bytes += n;
             t->buffered += n;
             R.total_buffered += n;
             t->out.push_back(pc);
@@ -238,7 +241,10 @@ static void run_task(Reader &R, const std::shared_ptr<Task> &t) {
             const uint8_t *mend = nullptr;
             const char *perr = "";
             io.progress = [&t, member](uint64_t off) { t->in_pos.store(member + off, std::memory_order_relaxed); };
-            if (!vf::inflate_member_parallel(R.file + member, file_end, R.par_threads, io, &mend, &perr)) { ok = false; err = perr; break; }
+            const double td = now_s();
+            const bool pok = vf::inflate_member_parallel(R.file + member, file_end, R.par_threads, io, &mend, &perr);
+            R.fq->inflate_ns += (uint64_t)((now_s() - td) * 1e9) * R.par_threads;      // (wall time of a decode all threads work on)
+            if (!pok) { ok = false; err = perr; break; }
             const uint64_t e = (uint64_t)(mend - R.file);
             t->in_pos.store(e, std::memory_order_relaxed);
             if (e >= R.size) { end = R.size; break; }
@@ -256,7 +262,10 @@ static void run_task(Reader &R, const std::shared_ptr<Task> &t) {
     while (ok) {
         if (kPiece - fill < 4096 && !flush_piece(false)) { ok = false; err = oom ? "out of memory: no buffer for inflated text" : "aborted"; break; }
         size_t got = 0;
+        const double td = now_s();
         const vf::GzipMemberDecoder::Status st = dec->run(piece.data + fill, kPiece - fill, &got);
+        R.fq->inflate_ns += (uint64_t)((now_s() - td) * 1e9);
+        R.fq->text_bytes += got;
         fill += got;
         t->in_pos.store((uint64_t)(dec->in_pos() - R.file), std::memory_order_relaxed);
         if (st == vf::GzipMemberDecoder::kError) { ok = false; err = dec->error(); break; }
@@ -333,8 +342,12 @@ static void run_task_zlib(Reader &R, const std::shared_ptr<Task> &t) {
         }
         z.next_out = piece.data + fill;
         z.avail_out = (uInt)(kPiece - fill);
+        const double td = now_s();
+        const size_t fill0 = fill;
         const int rc = inflate(&z, Z_NO_FLUSH);
         fill = kPiece - z.avail_out;
+        R.fq->inflate_ns += (uint64_t)((now_s() - td) * 1e9);
+        R.fq->text_bytes += fill - fill0;
         t->in_pos.store(pos - z.avail_in, std::memory_order_relaxed);
         if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) {
             ok = false; err = std::string("gzip error: ") + (z.msg ? z.msg : "corrupt stream"); break;
@@ -365,7 +378,6 @@ static void run_task_zlib(Reader &R, const std::shared_ptr<Task> &t) {
     R.cv.notify_all();
 }
 
-static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
 static const bool g_dbg = getenv("VFIND_FASTQ_DEBUG") != nullptr;
 
 static void inflate_worker(Reader &R) {
@@ -473,6 +485,10 @@ static int vf_run_fastq_impl(vf_ctx *c, const char *path) {
     if (fstat(fd, &st) != 0) { close(fd); return vf_internal_fail(VF_EIO, std::string(path) + ": fstat failed"); }
     Reader R;
     R.size = (uint64_t)st.st_size;
+    R.fq = vf_internal_fastq_stats(c);
+    const double t_call = now_s();
+    struct Wall { VfFastqStats *f; double t0; ~Wall() { f->wall_ns += (uint64_t)((now_s() - t0) * 1e9); } } wall{R.fq, t_call};
+    R.fq->comp_bytes += R.size;
     void *map = nullptr;
     if (R.size) {
         map = mmap(nullptr, R.size, PROT_READ, MAP_PRIVATE, fd, 0);
@@ -519,6 +535,7 @@ static int vf_run_fastq_impl(vf_ctx *c, const char *path) {
     // half as many frame + pack workers, whose per-read work is lighter; the environment can override the split
     auto env_u = [](const char *k, uint32_t dflt) { const char *e = getenv(k); const int v = e ? atoi(e) : 0; return v > 0 ? (uint32_t)v : dflt; };
     const uint32_t ninfl = env_u("VFIND_FASTQ_INFLATERS", nthreads);
+    R.fq->threads.store(ninfl);
     const uint32_t npack = env_u("VFIND_FASTQ_PACKERS", device_framing ? std::max<uint32_t>(1, (nthreads + 3) / 4) : std::max<uint32_t>(1, (nthreads + 1) / 2));
     std::vector<std::thread> inflaters;
     std::atomic<bool> watch_stop{false};
@@ -642,7 +659,10 @@ static int vf_run_fastq_impl(vf_ctx *c, const char *path) {
         }
         if (g_dbg) fprintf(stderr, "[fastq] sequencer emits chunk of %zu bytes at %.3f\n", cur->size, now_s());
         cur->final = final_flush;
-        if (!chunks.put(std::move(cur))) return false;
+        const double tq = now_s();
+        const bool put_ok = chunks.put(std::move(cur));
+        R.fq->queue_full_ns += (uint64_t)((now_s() - tq) * 1e9);
+        if (!put_ok) return false;
         cur = std::move(next);
         lines = carried_lines;
         return true;
@@ -671,7 +691,11 @@ static int vf_run_fastq_impl(vf_ctx *c, const char *path) {
             bool have = false, finished = false;
             {
                 std::unique_lock<std::mutex> lk(R.mu);
-                R.cv.wait(lk, [&] { return R.stop || !t->out.empty() || t->done; });
+                if (t->out.empty() && !t->done && !R.stop) {
+                    const double tw = now_s();
+                    R.cv.wait(lk, [&] { return R.stop || !t->out.empty() || t->done; });
+                    R.fq->seq_wait_ns += (uint64_t)((now_s() - tw) * 1e9);
+                }
                 if (R.stop) { ok = false; break; }
                 if (!t->out.empty()) {
                     p = t->out.front();
@@ -744,5 +768,8 @@ static int vf_run_fastq_impl(vf_ctx *c, const char *path) {
     chunks.close(false);
     for (auto &th : packers) th.join();
     join_all.f = nullptr;                      // everything is joined
-    return vf_sync(c);
+    const double td = now_s();
+    const int src = vf_sync(c);
+    R.fq->drain_ns += (uint64_t)((now_s() - td) * 1e9);
+    return src;
 }

@@ -70,7 +70,7 @@ struct vf_local_group;
 namespace {
 
 struct EventPair { hipEvent_t a, b; int kind; };
-enum { K_SCAN = 0, K_FILTER, K_DPW, K_DPREST, K_FIN, K_GEN, K_LOG, K_KINDS };
+enum { K_SCAN = 0, K_FILTER, K_DPW, K_DPREST, K_FIN, K_GEN, K_LOG, K_H2D, K_FRAME, K_KINDS };
 
 template <typename T> struct DevBuf {
     T *p = nullptr;
@@ -179,6 +179,7 @@ struct Slot {
     std::atomic<bool> in_flight{false};      // event recorded, not yet waited
     std::atomic<uint64_t> inflight_reads{0};  // reads of the batch `done` stands for (capacity_refresh)
     std::atomic<bool> cap_pending{false};     // those reads still count as possible new keys (capacity_retire takes them off)
+    std::atomic<uint64_t> cap_seq{0};         // batches noted on this slot: a retire decided on an earlier batch's event does not touch a later batch
     // fast path staging
     PinBuf<uint32_t> h_rows; PinBuf<uint16_t> h_lens;
     DevBuf<uint32_t> d_rows; DevBuf<uint16_t> d_lens;
@@ -261,15 +262,18 @@ struct vf_ctx {
     void *comm = nullptr;               // ncclComm_t of vf_comm_init
     vf_local_group *local_group = nullptr;   // or the in-process group of vf_comm_init_local (not owned)
     int comm_rank = 0, comm_world = 1;
+    PinBuf<uint64_t> h_hdr;             // header of a caller-owned blob, read in stream order (read_blob_header)
+    DevBuf<uint64_t> d_comm_words;      // status / size words of the exchange's all-gathers, allocated with the communicator
     // stats / profiling
     std::atomic<uint64_t> n_reads{0}, n_generic{0};
-    int profiling = 0;                  // 0 off, 1 every kernel bracket, 2 k_scan and k_finish only, 3 the same on every 3rd batch
-    std::atomic<uint32_t> prof_batch{0};   // batches seen by run_packed (mode 3 samples on it)
-    bool prof_this = false;                // mode 3: this batch is a sampled one (set by run_packed, read by Timed)
+    std::atomic<int> profiling{0};      // 0 off, 1 every kernel bracket, 2 k_scan and k_finish only, 3 the same on every 3rd batch
+    std::atomic<uint32_t> prof_batch{0};   // batches seen by run_packed (mode 3 samples on it; the decision is per call, Timed::sampled)
     std::mutex ev_mu;
     std::vector<EventPair> pending_events;
     double ms_result = 0;               // wall time of the latest vf_finish (export + device result build + copy back)
     uint64_t result_rows = 0;
+    uint64_t dup_rows = 0;              // entries the latest result build folded into another row (vf_stats.dup_rows)
+    VfFastqStats fq;                    // stage timers of vf_run_fastq
     double ms[K_KINDS] = {};
     uint64_t launches[K_KINDS] = {};
     // async error from worker threads
@@ -576,7 +580,7 @@ static void vf_ctx_destroy_impl(vf_ctx *c) {
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
-    c->exp_refs.release(); c->exp_counts.release(); c->d_part.release();
+    c->exp_refs.release(); c->exp_counts.release(); c->d_part.release(); c->d_comm_words.release(); c->h_hdr.release();
     vf_comm_release(c);
     c->t_slots.release(); c->t_counts.release(); c->t_arena.release(); c->t_counters.release(); c->t_chunks.release();
     c->spare.slots.release(); c->spare.counts.release(); c->spare.arena.release(); c->spare.counters.release(); c->spare.chunks.release();
@@ -605,7 +609,9 @@ static int resolve_events(vf_ctx *c) {
 }
 struct Timed {
     vf_ctx *c; hipStream_t s; int kind; hipEvent_t a = nullptr, b = nullptr; bool on;
-    Timed(vf_ctx *c_, hipStream_t s_, int k) : c(c_), s(s_), kind(k), on(c_->profiling == 1 || ((c_->profiling == 2 || (c_->profiling == 3 && c_->prof_this)) && (k == K_FIN || k == K_SCAN))) {
+    // mode = the profiling mode as the submitting call read it ONCE, sampled = that call's batch is one of mode 3's sampled
+    // ones: both decided per call (several threads may submit; a shared flag switched one batch's brackets from another's)
+    Timed(vf_ctx *c_, hipStream_t s_, int k, int mode, bool sampled) : c(c_), s(s_), kind(k), on(mode == 1 || ((mode == 2 || (mode == 3 && sampled)) && (k == K_FIN || k == K_SCAN))) {
         if (on) {
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
             (void)hipEventRecord(a, s);
@@ -722,15 +728,25 @@ static inline uint64_t arena_need(const vf_ctx *c, uint32_t len) {
 }
 // A batch has been enqueued on a slot: its reads count as possible new keys until the batch is seen to have finished.
 static void capacity_note_enqueued(vf_ctx *c, Slot *s, uint64_t n) {
-    s->inflight_reads = n;
-    { std::lock_guard<std::mutex> g(c->cap_mu); c->pending_reads += n; }
-    s->cap_pending = true;
+    {
+        std::lock_guard<std::mutex> g(c->cap_mu);
+        s->inflight_reads = n;
+        c->pending_reads += n;
+        s->cap_seq.fetch_add(1);
+        s->cap_pending = true;
+    }
     s->in_flight = true;
 }
-// ... and has finished (its `done` event is complete): the entry count it brought back stands for its reads from now on
-static void capacity_retire(vf_ctx *c, Slot *s) {
-    if (!s->cap_pending.exchange(false)) return;
+// ... and has finished (its `done` event is complete): the entry count it brought back stands for its reads from now on.
+// seq = the batch the caller saw finish (kAnySeq: the slot's owner, who has waited for the event itself).  Another thread's
+// refresh may have queried `done` just before the owner re-recorded it for the NEXT batch: without the sequence check it
+// would take the new batch's reads off the books and trust an entry count from before that batch.
+constexpr uint64_t kAnySeq = ~0ull;
+static void capacity_retire(vf_ctx *c, Slot *s, uint64_t seq = kAnySeq) {
     std::lock_guard<std::mutex> g(c->cap_mu);
+    if (!s->cap_pending.load()) return;
+    if (seq != kAnySeq && s->cap_seq.load() != seq) return;
+    s->cap_pending = false;
     const uint64_t n = s->inflight_reads.load();
     c->pending_reads -= std::min(c->pending_reads, n);
     if (s->h_entries.p && *s->h_entries.p > c->known_entries) c->known_entries = *s->h_entries.p;
@@ -743,9 +759,20 @@ static void capacity_retire(vf_ctx *c, Slot *s) {
 // each pair.  (Asking the device instead - a tiny kernel or copy on a stream of its own - waits behind whichever slot
 // shares its hardware queue, and that slot's kernels wait for its 47 MB copy: 5 ms.)
 static bool capacity_refresh(vf_ctx *c, uint64_t *upper_out) {
-    for (auto &L : c->res) if (L.stream && L.in_flight.load() && hipEventQuery(L.done) != hipSuccess) return false;   // resident batches are not in these books
-    for (auto &s : c->slots) if (s->cap_pending.load() && s->in_flight.load() && hipEventQuery(s->done) == hipSuccess) capacity_retire(c, s.get());
+    // resident batches (vf_process_device_packed) are not in these books while they run; once idle, the entry count their
+    // lane brought back is as good as a slot's (a context may mix the resident and the streaming API)
+    uint64_t res_known = 0;
+    for (auto &L : c->res) {
+        if (!L.stream) continue;
+        if (L.in_flight.load() && hipEventQuery(L.done) != hipSuccess) return false;
+        if (L.h_entries.p) res_known = std::max<uint64_t>(res_known, *L.h_entries.p);
+    }
+    for (auto &s : c->slots) {
+        const uint64_t seq = s->cap_seq.load();                        // before the query: a batch noted later has a later number
+        if (s->cap_pending.load() && s->in_flight.load() && hipEventQuery(s->done) == hipSuccess) capacity_retire(c, s.get(), seq);
+    }
     std::lock_guard<std::mutex> g(c->cap_mu);
+    if (res_known > c->known_entries) c->known_entries = res_known;
     const uint64_t fresh = c->known_entries + c->pending_reads + c->unenqueued;
     if (fresh < c->upper_entries) c->upper_entries = fresh;
     *upper_out = c->upper_entries;
@@ -776,7 +803,8 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
     if (count) { const int lrc = ws.ensure_log(n, c->main_stream); if (lrc) return lrc; }
     // every third batch: an odd period, so that the sampled batches alternate between the two batch lanes (every fourth sat on
     // one lane, always in the same phase against the other lane's k_finish: k_scan 0.515 ms against 0.43-0.47 over all launches)
-    if (c->profiling == 3) c->prof_this = c->prof_batch.fetch_add(1) % 3u == 0u;      // (a bench with one submitting thread)
+    const int pmode = c->profiling.load();
+    const bool psample = pmode == 3 && c->prof_batch.fetch_add(1) % 3u == 0u;
     BatchLists bl{};
     bl.listP = ws.listP.p; bl.listS = ws.listS.p; bl.listF = ws.listF.p;
     bl.cntP = ws.cnt.p; bl.cntS = ws.cnt.p + kMaxGrid; bl.cntF = ws.cnt.p + 2 * kMaxGrid;
@@ -791,7 +819,7 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
     // the spans test hook keeps the two searches independent, as find_adapter_match is called (lib.rs:278-286)
     ScanParams sp = c->sp; DpParams dpP = c->dpP, dpS = c->dpS;
     sp.independent = dpP.independent = dpS.independent = count ? 0u : 1u;
-    { Timed t(c, st, K_SCAN); HIP_TRY(launch_scan(st, W, d_rows, d_lens, n, sp, d_spans, bl)); }
+    { Timed t(c, st, K_SCAN, pmode, psample); HIP_TRY(launch_scan(st, W, d_rows, d_lens, n, sp, d_spans, bl)); }
     // per adapter: filter (block filter + Myers pass over what it leaves, one launch; the Myers pass alone where the scoring
     // gives the block filter no bound) -> every task class of the DP in one launch; or the full-width DP alone when the
     // scoring scheme gives no edit bound at all
@@ -800,13 +828,13 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
         const DpParams &dp = role == 0 ? dpP : dpS;
         if (c->filter_on) {
             {
-                Timed t(c, st, K_FILTER);
+                Timed t(c, st, K_FILTER, pmode, psample);
                 if (dp.nblk != 0 && c->block_filter) HIP_TRY(launch_bmfilter(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters));
                 else HIP_TRY(launch_filter(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters));
             }
-            { Timed t(c, st, K_DPW); HIP_TRY(launch_dp_classes(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters)); }
+            { Timed t(c, st, K_DPW, pmode, psample); HIP_TRY(launch_dp_classes(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters)); }
         } else {
-            Timed t(c, st, K_DPREST);
+            Timed t(c, st, K_DPREST, pmode, psample);
             HIP_TRY(launch_dp(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters));
         }
     }
@@ -822,7 +850,7 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
         // behind the other instead of all waiting for the same earlier record.
         std::lock_guard<std::mutex> fg(c->fin_mu);
         if (c->spare.valid && c->fin_recorded.load()) HIP_TRY(hipStreamWaitEvent(st, c->fin_event, 0));
-        { Timed t(c, st, K_FIN); HIP_TRY(launch_finish(st, W, d_rows, d_lens, n, d_spans, c->skip_translation, tab, ws.count_log())); }
+        { Timed t(c, st, K_FIN, pmode, psample); HIP_TRY(launch_finish(st, W, d_rows, d_lens, n, d_spans, c->skip_translation, tab, ws.count_log())); }
         if (c->spare.valid) { HIP_TRY(hipEventRecord(c->fin_event, st)); c->fin_recorded.store(true); }
     }
     if (count) {
@@ -833,7 +861,7 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
         std::lock_guard<std::mutex> g(c->log_mu);                       // one log's kernels at a time on the main stream
         HIP_TRY(hipStreamWaitEvent(c->main_stream, ws.log_written, 0));
         {
-            Timed t(c, c->main_stream, K_LOG);
+            Timed t(c, c->main_stream, K_LOG, pmode, psample);
             HIP_TRY(launch_count_log(c->main_stream, W, c->skip_translation, n, tab, ws.count_log()));
             const CountLog l = ws.count_log();                          // part totals and scatter cursors: zero for the next batch
             HIP_TRY(hipMemsetAsync(l.tot, 0, 4 * (size_t)kLogMaxParts * sizeof(uint32_t), c->main_stream));
@@ -869,7 +897,7 @@ static int run_generic(vf_ctx *c, Slot &s, uint64_t ng, uint64_t nbytes, uint32_
     Table tab = c->tab;
     tab.chunk_row = s.index;
     if (count) HIP_TRY(hipStreamWaitEvent(s.stream, c->clear_event, 0));
-    { Timed t(c, s.stream, K_GEN); HIP_TRY(launch_generic(s.stream, s.d_gbytes.p, s.d_goffs.p, ng, gp, ds, de, s.d_gws.p, threads, rows, tab)); }
+    { Timed t(c, s.stream, K_GEN, c->profiling.load(), false); HIP_TRY(launch_generic(s.stream, s.d_gbytes.p, s.d_goffs.p, ng, gp, ds, de, s.d_gws.p, threads, rows, tab)); }
     if (count && s.h_entries.p) HIP_TRY(launch_peek(s.stream, c->t_counters.p + C_ENTRIES, s.h_entries.p, 2));
     return VF_OK;
 }
@@ -1211,11 +1239,31 @@ static int vf_batch_submit_impl(vf_ctx *c, vf_batch *b, uint64_t n) {
 
 static int vf_process_device_packed_impl(vf_ctx *c, const void *d_rows, uint32_t W, const void *d_lens, uint64_t n, void *d_spans);
 extern "C" int vf_process_device_packed(vf_ctx *c, const void *d_rows, uint32_t W, const void *d_lens, uint64_t n, void *d_spans) { return vf_guard([&] { return vf_process_device_packed_impl(c, d_rows, W, d_lens, n, d_spans); }); }
+// reads per launch set of the resident path (VFIND_RES_SPLIT; 0 = a call's reads in one piece)
+static uint64_t res_split_reads() {
+    static const uint64_t v = [] { const char *e = getenv("VFIND_RES_SPLIT"); const long long x = e ? atoll(e) : 0; return (uint64_t)(x > 0 ? std::max<long long>(x, 65536) : 0); }();
+    return v;
+}
+static int process_device_piece(vf_ctx *c, const uint32_t *d_rows, uint32_t W, const uint16_t *d_lens, uint64_t n, short2 *d_spans);
 static int vf_process_device_packed_impl(vf_ctx *c, const void *d_rows, uint32_t W, const void *d_lens, uint64_t n, void *d_spans) {
     if (!c || (n && (!d_rows || !d_lens))) return fail(VF_EINVAL, "null argument");
     if (!c->fast_ok) return fail(VF_EINVAL, "these adapters/scores need the byte-wise path: use vf_submit_ascii");
     if (W != 10 && W != 20 && W != 40) return fail(VF_EINVAL, "row_dwords must be 10, 20 or 40");
     HIP_TRY(hipSetDevice(c->dev));
+    // A resident batch may be cut into pieces that go down the batch lanes one after the other: a piece's rows are read by
+    // k_scan, gathered from by the filter and DP kernels and streamed again by k_finish - pieces small enough for the rows of
+    // the pieces in flight (and the table) to stay in the 256 MiB Infinity Cache make every visit after the first an on-die hit.
+    const uint64_t piece = res_split_reads();
+    if (piece == 0 || n <= piece + piece / 2) return process_device_piece(c, (const uint32_t *)d_rows, W, (const uint16_t *)d_lens, n, (short2 *)d_spans);
+    const uint64_t k = (n + piece - 1) / piece, each = ((n + k - 1) / k + 255) & ~255ull;      // equal pieces, whole workgroups
+    for (uint64_t at = 0; at < n; at += each) {
+        const uint64_t m = std::min(each, n - at);
+        const int rc = process_device_piece(c, (const uint32_t *)d_rows + at * W, W, (const uint16_t *)d_lens + at, m, d_spans ? (short2 *)d_spans + at : nullptr);
+        if (rc) return rc;
+    }
+    return VF_OK;
+}
+static int process_device_piece(vf_ctx *c, const uint32_t *d_rows, uint32_t W, const uint16_t *d_lens, uint64_t n, short2 *d_spans) {
     int rc;
     ResLane &L = c->res[c->res_next++ % c->n_res];
     if (L.in_flight && hipEventQuery(L.done) == hipSuccess) {           // lane idle: its entry count is current
@@ -1223,8 +1271,8 @@ static int vf_process_device_packed_impl(vf_ctx *c, const void *d_rows, uint32_t
     }
     std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
     if ((rc = L.ws.ensure(n))) return rc;
-    short2 *spans = d_spans ? (short2 *)d_spans : L.ws.spans.p;
-    if ((rc = run_packed(c, L.stream, L.chunk_row, L.ws, (const uint32_t *)d_rows, (int)W, (const uint16_t *)d_lens, n, spans, true, L.h_entries.p))) return rc;
+    short2 *spans = d_spans ? d_spans : L.ws.spans.p;
+    if ((rc = run_packed(c, L.stream, L.chunk_row, L.ws, d_rows, (int)W, d_lens, n, spans, true, L.h_entries.p))) return rc;
     HIP_TRY(hipEventRecord(L.done, L.stream));
     L.inflight_reads = n;
     L.in_flight = true;
@@ -1255,6 +1303,7 @@ static int check_device_errors(vf_ctx *c, uint64_t *counters_out) {
     if (h[C_ERROR] & 4) return fail(VF_ECAPACITY, "a variant region exceeds 65535 symbols");
     if (h[C_ERROR] & 8) return fail(VF_EDEVICE, "count log: part totals and entries disagree (internal error)");
     if (h[C_ERROR] & 16) return fail(VF_EDEVICE, "key cache: occurrences of a key whose insert failed (internal error)");
+    if (h[C_ERROR] & 32) return fail(VF_EINVAL, "merge: the blob holds byte keys with non-ASCII bytes, which a translating context's table cannot store (was it exported with skip_translation?)");
     return VF_OK;
 }
 
@@ -1419,6 +1468,20 @@ static int vf_table_partition_export_impl(vf_ctx *c, uint32_t world, uint32_t ow
     return export_blob(c, world, owner, c->part[2 * owner], c->part[2 * owner + 1], d_dst, capacity, written);
 }
 
+// The 16-byte header of a blob the CALLER owns, read in stream order on the main stream - behind whatever vf_wait_stream made
+// a dependency of it (a collective still writing the buffer on a stream of the caller's) - through a one-wave kernel into
+// page-locked memory.  A blocking hipMemcpy on the null stream is ordered with none of that on a non-blocking stream: it
+// could bring back a stale header, and a wrong or zero entry count loses counts silently (the bug class vf_wait_stream was
+// added to close).
+static int read_blob_header(vf_ctx *c, const void *d_blob, uint64_t hdr[2]) {
+    int rc;
+    if ((rc = c->h_hdr.ensure(2))) return rc;
+    HIP_TRY(launch_peek(c->main_stream, d_blob, c->h_hdr.p, 4));
+    HIP_TRY(hipStreamSynchronize(c->main_stream));
+    hdr[0] = c->h_hdr.p[0]; hdr[1] = c->h_hdr.p[1];
+    return VF_OK;
+}
+
 // header of an exported table as a peer sent it: checked without overflow before anything is sized from it
 static int blob_header_ok(const uint64_t hdr[2], uint64_t nbytes) {
     if (nbytes < 16) return fail(VF_EINVAL, "blob too small");
@@ -1434,8 +1497,8 @@ static int vf_table_merge_impl(vf_ctx *c, const void *d_blob, uint64_t nbytes) {
     HIP_TRY(hipSetDevice(c->dev));
     if (nbytes < 16) return fail(VF_EINVAL, "blob too small");
     uint64_t hdr[2];
-    HIP_TRY(hipMemcpy(hdr, d_blob, 16, hipMemcpyDeviceToHost));
     int rc;
+    if ((rc = read_blob_header(c, d_blob, hdr))) return rc;
     if ((rc = blob_header_ok(hdr, nbytes))) return rc;
     // every peer entry may be a new key (and every key dword may belong to a LONG key): make room first, exactly as a
     // streaming submit does -- a table sized for one rank's keys would otherwise fill up under seven peers' tables
@@ -1469,6 +1532,8 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                          // (optional: absent in very old builds)
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;  // (optional)
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -1486,6 +1551,8 @@ Rccl *rccl() {
         r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
         r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.CommAbort = (decltype(r.CommAbort))sym("ncclCommAbort");
+        r.CommGetAsyncError = (decltype(r.CommGetAsyncError))sym("ncclCommGetAsyncError");
         r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
         r.Send = (decltype(r.Send))sym("ncclSend");
         r.Recv = (decltype(r.Recv))sym("ncclRecv");
@@ -1504,6 +1571,14 @@ Rccl *rccl() {
             return fail(VF_EDEVICE, std::string(#expr) + ": " + (R->GetErrorString ? R->GetErrorString(_r) : "RCCL error")); \
     } while (0)
 
+// test hook: VFIND_TEST_FAIL_ALLREDUCE=<rank>:<step> makes that rank fail at local step 1 (buckets), 2 (buffers) or 3 (share),
+// or - step 4 - in a send INSIDE the first round's begin/end bracket (LocalTransport)
+static bool allreduce_test_fail(int rank, int step) {
+    const char *e = getenv("VFIND_TEST_FAIL_ALLREDUCE");
+    int r = -1, s = -1;
+    return e && sscanf(e, "%d:%d", &r, &s) == 2 && r == rank && s == step;
+}
+
 // ---- transports of the exchange ---------------------------------------------------------------------------------------
 // vf_table_allreduce is written against these five calls.  RcclTransport is the product path (one process per GPU, xGMI);
 // LocalTransport connects contexts of ONE process - a host that drives several GPUs from one process, and the tests, where
@@ -1520,16 +1595,67 @@ struct Transport {
     virtual int send(const void *p, size_t bytes, int peer, hipStream_t st) = 0;
     virtual int recv(void *p, size_t bytes, int peer, hipStream_t st) = 0;
     virtual int end(hipStream_t st) = 0;
+    // what has been enqueued on `st` has completed, or the transport has given up on it (a peer that failed, a deadline):
+    // the wait every rank does behind a collective or a round - never an unbounded hipStreamSynchronize
+    virtual int wait(hipStream_t st) = 0;
+    // This rank is leaving with an error: a round left open between begin() and end() is closed, and the communicator is
+    // broken so that no peer stays blocked on this rank (and this rank on no peer).  Safe to call in any state, once or more;
+    // the transport is unusable afterwards.  The caller's error message is kept.
+    virtual void abort() = 0;
 };
 
+// seconds a rank waits for a collective or a round of the exchange before it gives up on its peers (0 = for ever)
+static double exchange_timeout_s() {
+    static const double t = [] { const char *e = getenv("VFIND_EXCHANGE_TIMEOUT_S"); const double v = e ? atof(e) : 120.0; return v >= 0. ? v : 120.0; }();
+    return t;
+}
+
 struct RcclTransport : Transport {
-    Rccl *R; ncclComm_t comm;
-    RcclTransport(Rccl *r, ncclComm_t c) : R(r), comm(c) {}
+    Rccl *R; ncclComm_t comm; void **owner;      // owner: the context's handle, cleared when the communicator is aborted
+    bool in_group = false, dead = false;
+    RcclTransport(Rccl *r, ncclComm_t c, void **owner_) : R(r), comm(c), owner(owner_) {}
     int all_gather(const uint64_t *send, uint64_t *recv, size_t count, hipStream_t st) override { NCCL_TRY(R->AllGather(send, recv, count, ncclUint64, comm, st)); return VF_OK; }
-    int begin() override { NCCL_TRY(R->GroupStart()); return VF_OK; }
+    int begin() override { NCCL_TRY(R->GroupStart()); in_group = true; return VF_OK; }
     int send(const void *p, size_t bytes, int peer, hipStream_t st) override { NCCL_TRY(R->Send(p, bytes, ncclUint8, peer, comm, st)); return VF_OK; }
     int recv(void *p, size_t bytes, int peer, hipStream_t st) override { NCCL_TRY(R->Recv(p, bytes, ncclUint8, peer, comm, st)); return VF_OK; }
-    int end(hipStream_t) override { NCCL_TRY(R->GroupEnd()); return VF_OK; }
+    int end(hipStream_t) override { in_group = false; NCCL_TRY(R->GroupEnd()); return VF_OK; }
+    // The stream is polled, never waited for blindly: a peer that has gone (its process died, it aborted its communicator)
+    // leaves this rank's collective kernel spinning for ever.  RCCL reports what it notices through ncclCommGetAsyncError;
+    // what it does not notice ends at the deadline.  Either way the communicator is aborted - that is what makes the
+    // kernel leave - and the call returns an error.
+    int wait(hipStream_t st) override {
+        const auto t0 = std::chrono::steady_clock::now();
+        const double limit = exchange_timeout_s();
+        for (unsigned spin = 0;; ++spin) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) return VF_OK;
+            if (q != hipErrorNotReady) { (void)hipGetLastError(); const int rc = fail(VF_EDEVICE, std::string("table exchange: ") + hipGetErrorString(q)); abort(); return rc; }
+            if (R->CommGetAsyncError && (spin & 63u) == 63u) {
+                ncclResult_t ar = ncclSuccess;
+                if (R->CommGetAsyncError(comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+                    const int rc = fail(VF_EDEVICE, std::string("table exchange: RCCL reports an asynchronous error: ") + (R->GetErrorString ? R->GetErrorString(ar) : "?"));
+                    abort();
+                    return rc;
+                }
+            }
+            if (limit > 0. && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+                const int rc = fail(VF_EDEVICE, "table exchange: no completion within VFIND_EXCHANGE_TIMEOUT_S (" + std::to_string((int)limit) + " s): a peer has gone; communicator aborted");
+                abort();
+                return rc;
+            }
+            if (spin < 2000u) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    }
+    void abort() override {
+        const std::string keep = g_err;
+        if (in_group) { in_group = false; (void)R->GroupEnd(); }       // an open ncclGroupStart would swallow every later call of this thread
+        if (!dead) {
+            dead = true;
+            if (R->CommAbort) (void)R->CommAbort(comm); else (void)R->CommDestroy(comm);
+            if (owner) *owner = nullptr;                                // (freed: vf_comm_release must not destroy it again)
+        }
+        g_err = keep;
+    }
 };
 }  // namespace
 
@@ -1584,8 +1710,13 @@ struct LocalTransport : Transport {
         if (!g->barrier()) return broken();                  // nobody reuses its send buffer before everyone has copied
         return VF_OK;
     }
+    int wait(hipStream_t st) override { HIP_TRY(hipStreamSynchronize(st)); return VF_OK; }     // (device-to-device copies of this process)
+    void abort() override { const std::string keep = g_err; ops.clear(); g->abort(); g_err = keep; }   // peers waiting at the rendezvous leave too
     int begin() override { ops.clear(); return VF_OK; }
-    int send(const void *p, size_t bytes, int peer, hipStream_t) override { ops.push_back({true, const_cast<void *>(p), bytes, peer}); return VF_OK; }
+    int send(const void *p, size_t bytes, int peer, hipStream_t) override {
+        if (allreduce_test_fail(me, 4)) return fail(VF_EDEVICE, "injected failure inside a round (VFIND_TEST_FAIL_ALLREDUCE)");
+        ops.push_back({true, const_cast<void *>(p), bytes, peer}); return VF_OK;
+    }
     int recv(void *p, size_t bytes, int peer, hipStream_t) override { ops.push_back({false, p, bytes, peer}); return VF_OK; }
     int end(hipStream_t st) override {
         HIP_TRY(hipStreamSynchronize(st));
@@ -1615,6 +1746,11 @@ struct LocalTransport : Transport {
 };
 }  // namespace
 
+// staging of the exchange's status words for a communicator of `world` ranks (allreduce_over): G sizes + status per rank, G ranks
+static int comm_words_ensure(vf_ctx *c, int world) {
+    const size_t W1 = (size_t)world + 1;
+    return c->d_comm_words.ensure(W1 + W1 * (size_t)world + 16);
+}
 static void vf_comm_release(vf_ctx *c) {
     if (c->comm) { if (Rccl *R = rccl()) (void)R->CommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
     c->local_group = nullptr;
@@ -1643,6 +1779,7 @@ static int vf_comm_init_impl(vf_ctx *c, int rank, int world, const void *id128) 
     if (!R) return fail(VF_EDEVICE, "librccl.so.1 is not loadable");
     HIP_TRY(hipSetDevice(c->dev));
     vf_comm_release(c);
+    { const int wrc = comm_words_ensure(c, world); if (wrc) return wrc; }
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     ncclComm_t comm = nullptr;
@@ -1672,15 +1809,10 @@ static int vf_comm_init_local_impl(vf_ctx *c, int rank, vf_local_group *g) {
     if (!c || !g) return fail(VF_EINVAL, "null argument");
     if (rank < 0 || rank >= g->world) return fail(VF_EINVAL, "rank out of range for this group");
     vf_comm_release(c);
+    HIP_TRY(hipSetDevice(c->dev));
+    { const int wrc = comm_words_ensure(c, g->world); if (wrc) return wrc; }
     c->local_group = g; c->comm_rank = rank; c->comm_world = g->world;
     return VF_OK;
-}
-
-// test hook: VFIND_TEST_FAIL_ALLREDUCE=<rank>:<step> makes that rank fail at local step 1 (buckets), 2 (buffers) or 3 (share)
-static bool allreduce_test_fail(int rank, int step) {
-    const char *e = getenv("VFIND_TEST_FAIL_ALLREDUCE");
-    int r = -1, s = -1;
-    return e && sscanf(e, "%d:%d", &r, &s) == 2 && r == rank && s == step;
 }
 
 // Owner-partitioned reduce of the count tables of all ranks (primary design; the multi-GPU form of the serial
@@ -1701,10 +1833,12 @@ static int allreduce_over(vf_ctx *c, Transport &T, int root) {
     const int G = c->comm_world, me = c->comm_rank;
     hipStream_t st = c->main_stream;
     DevBuf<uint8_t> sendbuf, recvbuf, sharebuf, gatherbuf;
-    DevBuf<uint64_t> d_words;
-    struct Free { DevBuf<uint8_t> &a, &b, &c2, &d; DevBuf<uint64_t> &e; ~Free() { a.release(); b.release(); c2.release(); d.release(); e.release(); } } fr{sendbuf, recvbuf, sharebuf, gatherbuf, d_words};
+    struct Free { DevBuf<uint8_t> &a, &b, &c2, &d; ~Free() { a.release(); b.release(); c2.release(); d.release(); } } fr{sendbuf, recvbuf, sharebuf, gatherbuf};
     const size_t W1 = (size_t)G + 1;                                   // words a rank contributes to all-gather 1: G sizes + status
-    int rc = d_words.ensure(W1 + W1 * (size_t)G + 2 * ((size_t)G + 1));
+    // The staging of the status words was allocated when the communicator was made (comm_words_ensure): the one thing the
+    // "every rank leaves together" promise cannot survive is a rank that cannot SAY it has failed.
+    DevBuf<uint64_t> &d_words = c->d_comm_words;
+    if (d_words.cap < W1 + W1 * (size_t)G) return fail(VF_EINVAL, "table exchange: the communicator has no staging words (vf_comm_init / vf_comm_init_local)");
     // statuses of all ranks after a gather of `words` words per rank whose last word is the status; VF_OK only if all are
     auto agreed = [&](const std::vector<uint64_t> &all, size_t words, int mine) -> int {
         if (mine) return mine;                                         // (own message already set)
@@ -1713,18 +1847,30 @@ static int allreduce_over(vf_ctx *c, Transport &T, int root) {
                 return fail((int)all[(size_t)r * words + words - 1], "table exchange: rank " + std::to_string(r) + " failed (" + std::to_string(all[(size_t)r * words + words - 1]) + "), every rank leaves");
         return VF_OK;
     };
+    // a transport call failed, or a wait gave up: close what is open, break the communicator (no peer stays blocked on this rank)
+    auto broken = [&](int code) -> int { T.abort(); return code; };
     auto gather_words = [&](const std::vector<uint64_t> &mine_w, std::vector<uint64_t> &all_w) -> int {
         const size_t words = mine_w.size();
         all_w.assign(words * (size_t)G, 0);
-        if (!d_words.p) return fail(VF_ENOMEM, "hipMalloc failed");    // (without the staging words there is no way to tell the peers)
-        HIP_TRY(hipMemcpyAsync(d_words.p, mine_w.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        if (hipMemcpyAsync(d_words.p, mine_w.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess) return broken(fail(VF_EDEVICE, "hipMemcpyAsync failed"));
         int r2 = T.all_gather(d_words.p, d_words.p + words, words, st);
-        if (r2) return r2;
-        HIP_TRY(hipMemcpyAsync(all_w.data(), d_words.p + words, words * (size_t)G * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        if (r2) return broken(r2);
+        if (hipMemcpyAsync(all_w.data(), d_words.p + words, words * (size_t)G * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) return broken(fail(VF_EDEVICE, "hipMemcpyAsync failed"));
+        if ((r2 = T.wait(st))) return broken(r2);
         return VF_OK;
     };
-    if (rc) return rc;                                                 // (nothing collective has started: the peers time out in their own way)
+    // one round: the bracket is closed on every way out (an error between ncclGroupStart and ncclGroupEnd used to return with the
+    // group open and the peers inside their ncclGroupEnd)
+    auto round = [&](auto &&body) -> int {
+        int r2 = T.begin();
+        if (r2) return broken(r2);
+        r2 = body();
+        if (r2) return broken(r2);                                     // (abort() closes the open round first)
+        if ((r2 = T.end(st))) return broken(r2);
+        if ((r2 = T.wait(st))) return broken(r2);
+        return VF_OK;
+    };
+    int rc = VF_OK;
 
     // 1. buckets
     std::vector<uint64_t> mine(G, 0), soff(G + 1, 0);
@@ -1761,15 +1907,15 @@ static int allreduce_over(vf_ctx *c, Transport &T, int root) {
     if ((rc = agreed(all2, 1, rc))) return rc;
 
     // 3. bucket `me` of every rank comes here
-    if ((rc = T.begin())) return rc;
-    for (int p = 0; p < G && !rc; ++p) {
-        if (p == me) continue;
-        rc = T.send(sendbuf.p + soff[p], mine[p], p, st);
-        if (!rc) rc = T.recv(recvbuf.p + roff[p], bucket(p, me), p, st);
-    }
-    if (!rc) rc = T.end(st);
-    if (rc) return rc;                                                 // (the transport itself failed: nothing to agree over)
-    HIP_TRY(hipStreamSynchronize(st));
+    if ((rc = round([&]() -> int {
+            int r2 = VF_OK;
+            for (int p = 0; p < G && !r2; ++p) {
+                if (p == me) continue;
+                r2 = T.send(sendbuf.p + soff[p], mine[p], p, st);
+                if (!r2) r2 = T.recv(recvbuf.p + roff[p], bucket(p, me), p, st);
+            }
+            return r2;
+        }))) return rc;                                                // (the transport itself failed: communicator aborted, nothing to agree over)
 
     // 4. this rank's share
     if (allreduce_test_fail(me, 3)) rc = fail(VF_ENOMEM, "injected failure (VFIND_TEST_FAIL_ALLREDUCE)");
@@ -1788,17 +1934,16 @@ static int allreduce_over(vf_ctx *c, Transport &T, int root) {
     if ((rc = agreed(all3, 2, rc))) return rc;
 
     // 5. shares to root
-    if ((rc = T.begin())) return rc;
-    if (me != root) rc = T.send(sharebuf.p, share, root, st);
-    else
-        for (int q = 0; q < G && !rc; ++q) {
-            if (q == me) continue;
-            if (all3[(size_t)q * 2] > gcap[q + 1] - gcap[q]) rc = fail(VF_EDEVICE, "table exchange: a share is larger than its parts (internal error)");
-            else rc = T.recv(gatherbuf.p + gcap[q], all3[(size_t)q * 2], q, st);
-        }
-    if (!rc) rc = T.end(st);
-    if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(st));
+    if ((rc = round([&]() -> int {
+            if (me != root) return T.send(sharebuf.p, share, root, st);
+            int r2 = VF_OK;
+            for (int q = 0; q < G && !r2; ++q) {
+                if (q == me) continue;
+                if (all3[(size_t)q * 2] > gcap[q + 1] - gcap[q]) r2 = fail(VF_EDEVICE, "table exchange: a share is larger than its parts (internal error)");
+                else r2 = T.recv(gatherbuf.p + gcap[q], all3[(size_t)q * 2], q, st);
+            }
+            return r2;
+        }))) return rc;
     if (me == root)
         for (int q = 0; q < G; ++q)
             if (q != me && (rc = vf_table_merge(c, gatherbuf.p + gcap[q], all3[(size_t)q * 2]))) return rc;
@@ -1817,12 +1962,14 @@ static int vf_table_allreduce_impl(vf_ctx *c, int root) {
     if (c->local_group) {
         LocalTransport T(c->local_group, c->comm_rank, c->dev);
         const int rc = allreduce_over(c, T, root);
-        if (rc) { const std::string keep = g_err; c->local_group->abort(); g_err = keep; }      // peers waiting at the rendezvous leave too
+        if (rc) T.abort();                                   // peers waiting at the rendezvous leave too (the message is kept)
         return rc;
     }
     Rccl *R = rccl();
     if (!R) return fail(VF_EDEVICE, "librccl.so.1 is not loadable");
-    RcclTransport T(R, (ncclComm_t)c->comm);
+    RcclTransport T(R, (ncclComm_t)c->comm, &c->comm);
+    // A rank that leaves with an error of its OWN between two collectives has said so in a status word and its peers leave
+    // with it: the communicator stays usable.  A transport error or a deadline has aborted it inside allreduce_over.
     return allreduce_over(c, T, root);
 }
 
@@ -1854,6 +2001,7 @@ static int vf_finish_impl(vf_ctx *c, vf_result **out) {
     if (rc) return fail(rc, err);
     c->ms_result = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c->result_rows = r->counts.size();
+    c->dup_rows = r->dup_rows;
     *out = r.release();
     return VF_OK;
 }
@@ -1870,10 +2018,15 @@ static int vf_finish_blobs_impl(vf_ctx *c, const void *const *d_blobs, const uin
     int rc;
     std::vector<uint64_t> n(n_blobs), adw(n_blobs);
     uint64_t tot_n = 0, tot_adw = 0;
+    // the headers in stream order, behind whatever vf_wait_stream queued on the main stream (read_blob_header)
+    if ((rc = c->h_hdr.ensure(2 * (size_t)n_blobs + 2))) return rc;
     for (uint32_t k = 0; k < n_blobs; ++k) {
         if (!d_blobs[k] || nbytes[k] < 16) return fail(VF_EINVAL, "blob too small");
-        uint64_t hdr[2];
-        HIP_TRY(hipMemcpy(hdr, d_blobs[k], 16, hipMemcpyDeviceToHost));
+        HIP_TRY(launch_peek(c->main_stream, d_blobs[k], c->h_hdr.p + 2 * (size_t)k, 4));
+    }
+    HIP_TRY(hipStreamSynchronize(c->main_stream));
+    for (uint32_t k = 0; k < n_blobs; ++k) {
+        const uint64_t hdr[2] = {c->h_hdr.p[2 * (size_t)k], c->h_hdr.p[2 * (size_t)k + 1]};
         if ((rc = blob_header_ok(hdr, nbytes[k]))) return rc;
         n[k] = hdr[0]; adw[k] = hdr[1];
         tot_n += hdr[0]; tot_adw += hdr[1];
@@ -1898,6 +2051,7 @@ static int vf_finish_blobs_impl(vf_ctx *c, const void *const *d_blobs, const uin
     if (rc) return fail(rc, err);
     c->ms_result = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c->result_rows = r->counts.size();
+    c->dup_rows = r->dup_rows;
     *out = r.release();
     return VF_OK;
 }
@@ -1937,6 +2091,13 @@ static int vf_stats_get_impl(vf_ctx *c, vf_stats *o) {
     o->launches_dp_window = c->launches[K_DPW]; o->launches_dp_rest = c->launches[K_DPREST];
     o->launches_finish = c->launches[K_FIN]; o->launches_generic = c->launches[K_GEN];
     o->ms_count_log = c->ms[K_LOG]; o->launches_count_log = c->launches[K_LOG];
+    o->dup_rows = c->dup_rows;
+    const VfFastqStats &f = c->fq;
+    o->fq_wall_ms = f.wall_ns.load() * 1e-6; o->fq_inflate_ms = f.inflate_ns.load() * 1e-6; o->fq_seq_wait_ms = f.seq_wait_ns.load() * 1e-6;
+    o->fq_queue_full_ms = f.queue_full_ns.load() * 1e-6; o->fq_submit_ms = f.submit_ns.load() * 1e-6; o->fq_slot_wait_ms = f.slot_wait_ns.load() * 1e-6;
+    o->fq_index_wait_ms = f.index_wait_ns.load() * 1e-6; o->fq_drain_ms = f.drain_ns.load() * 1e-6;
+    o->fq_comp_bytes = f.comp_bytes.load(); o->fq_text_bytes = f.text_bytes.load(); o->fq_inflate_threads = f.threads.load(); o->fq_chunks = f.chunks.load();
+    o->ms_h2d = c->ms[K_H2D]; o->launches_h2d = c->launches[K_H2D]; o->ms_frame = c->ms[K_FRAME]; o->launches_frame = c->launches[K_FRAME];
     return VF_OK;
 }
 static int vf_stats_reset_impl(vf_ctx *c);
@@ -1947,6 +2108,7 @@ static int vf_stats_reset_impl(vf_ctx *c) {
     if (rc && rc != VF_ECAPACITY) return rc;
     c->n_reads = 0; c->n_generic = 0;
     for (int k = 0; k < K_KINDS; ++k) { c->ms[k] = 0; c->launches[k] = 0; }
+    c->fq.reset();
     const uint64_t z[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(c->t_counters.p + C_ACCEPTED, z, 4 * sizeof(uint64_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->t_counters.p + C_SLOW, z, sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -1972,6 +2134,7 @@ static int vf_set_profiling_impl(vf_ctx *c, int on) {
 // ------------------------------------------------------------------------------------------------
 // A chunk of whole FASTQ records (byte ranges of inflated text): copied into pinned staging, sent to the
 // device, indexed by line, framed and packed there (k_nl_*, k_frame_pack), then the usual batch path.
+VfFastqStats *vf_internal_fastq_stats(vf_ctx *c) { return &c->fq; }
 bool vf_internal_device_framing(const vf_ctx *) {
     static const bool on = [] { const char *e = getenv("VFIND_FASTQ_DEVICE_FRAMING"); return !e || atoi(e) != 0; }();
     return on;
@@ -1990,10 +2153,15 @@ int vf_internal_submit_text(vf_ctx *c, const TextSpan *spans, size_t n_spans, bo
     if (total == 0) return VF_OK;
     if (total > 0x7FFFFFF0ull) return fail(VF_EINVAL, "text chunk too large");
     HIP_TRY(hipSetDevice(c->dev));
+    const auto t_in = std::chrono::steady_clock::now();
+    auto ns_since = [](std::chrono::steady_clock::time_point t0) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); };
+    struct Whole { vf_ctx *c; std::chrono::steady_clock::time_point t0; ~Whole() { c->fq.submit_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); c->fq.chunks += 1; } } whole{c, t_in};
     Slot *s = acquire_slot(c);
     struct Rel { vf_ctx *c; Slot *s; ~Rel() { release_slot(c, s); } } rel{c, s};
     int rc;
     if ((rc = wait_slot(c, s))) return rc;
+    c->fq.slot_wait_ns += ns_since(t_in);
+    const int pmode = c->profiling.load();
     // final chunk: trailing newlines are padding, and the last record may lack its newline
     size_t n_use = n_spans;
     size_t last_n = n_spans ? spans[n_spans - 1].n : 0;
@@ -2017,6 +2185,8 @@ int vf_internal_submit_text(vf_ctx *c, const TextSpan *spans, size_t n_spans, bo
     if ((rc = s->d_line_end.ensure(total + 1))) return rc;
     if ((rc = s->d_info.ensure(4))) return rc;
     if ((rc = s->h_info.ensure(4))) return rc;
+    {
+    Timed th2d(c, s->stream, K_H2D, pmode, false);
     if (spans_pinned) {
         // the pieces are page-locked: the DMA engine reads them directly (they stay referenced until this call returns,
         // and the stream is waited for below)
@@ -2038,9 +2208,10 @@ int vf_internal_submit_text(vf_ctx *c, const TextSpan *spans, size_t n_spans, bo
         if (add_nl) s->h_text.p[at] = '\n';
         HIP_TRY(hipMemcpyAsync(s->d_text.p, s->h_text.p, total, hipMemcpyHostToDevice, s->stream));
     }
-    HIP_TRY(launch_line_index(s->stream, s->d_text.p, total, s->d_tile_cnt.p, s->d_tile_off.p, s->d_line_end.p, s->d_info.p));
+    }
+    { Timed tf(c, s->stream, K_FRAME, pmode, false); HIP_TRY(launch_line_index(s->stream, s->d_text.p, total, s->d_tile_cnt.p, s->d_tile_off.p, s->d_line_end.p, s->d_info.p)); }
     HIP_TRY(launch_peek(s->stream, s->d_info.p, s->h_info.p, 2));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    { const auto tw = std::chrono::steady_clock::now(); HIP_TRY(hipStreamSynchronize(s->stream)); c->fq.index_wait_ns += ns_since(tw); }
     const uint32_t n_lines = s->h_info.p[0], max_line = s->h_info.p[1];
     if (n_lines % 4u) return fail(VF_EFORMAT, "malformed FASTQ: truncated record");
     const uint64_t n = n_lines / 4u;
@@ -2056,8 +2227,9 @@ int vf_internal_submit_text(vf_ctx *c, const TextSpan *spans, size_t n_spans, bo
     if ((rc = s->d_gen_start.ensure(n))) return rc;
     if ((rc = s->d_gen_len.ensure(n))) return rc;
     // adapters / scores outside the 2-bit path: every read goes the byte-wise way (frame_pack lists reads longer than 0 rows)
-    HIP_TRY(launch_frame_pack(s->stream, c->fast_ok ? (int)W : 10, s->d_text.p, s->d_line_end.p, (uint32_t)n, s->d_rows.p, s->d_lens.p,
-                              s->d_gen_start.p, s->d_gen_len.p, s->d_info.p, !c->fast_ok));
+    { Timed tf(c, s->stream, K_FRAME, pmode, false);
+      HIP_TRY(launch_frame_pack(s->stream, c->fast_ok ? (int)W : 10, s->d_text.p, s->d_line_end.p, (uint32_t)n, s->d_rows.p, s->d_lens.p,
+                                s->d_gen_start.p, s->d_gen_len.p, s->d_info.p, !c->fast_ok)); }
     c->n_reads += n;
     if (c->fast_ok) {
         if ((rc = run_packed(c, s->stream, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, n, s->ws.spans.p, true, s->h_entries.p))) return rc;
@@ -2072,7 +2244,7 @@ int vf_internal_submit_text(vf_ctx *c, const TextSpan *spans, size_t n_spans, bo
         Table tab = c->tab;
         tab.chunk_row = s->index;
         HIP_TRY(hipStreamWaitEvent(s->stream, c->clear_event, 0));
-        Timed t(c, s->stream, K_GEN);
+        Timed t(c, s->stream, K_GEN, c->profiling.load(), false);
         HIP_TRY(launch_generic_indexed(s->stream, s->d_text.p, s->d_gen_start.p, s->d_gen_len.p, s->d_info.p + 3, gp, s->d_gws.p, threads, rows, tab));
     }
     HIP_TRY(launch_peek(s->stream, s->d_info.p, s->h_info.p, 4));

@@ -27,6 +27,15 @@ int vf_internal_fail(int code, const std::string &msg);      // sets the calling
 std::string vf_internal_last_error();
 int vf_internal_fail_noexcept(int code, const char *msg) noexcept;   // the same for a message that must not allocate
 
+// stage timers of vf_run_fastq (vf_stats.fq_*): nanoseconds / bytes, added to by the reader's threads
+#include <atomic>
+struct VfFastqStats {
+    std::atomic<uint64_t> wall_ns{0}, inflate_ns{0}, seq_wait_ns{0}, queue_full_ns{0}, submit_ns{0}, slot_wait_ns{0}, index_wait_ns{0}, drain_ns{0};
+    std::atomic<uint64_t> comp_bytes{0}, text_bytes{0}, threads{0}, chunks{0};
+    void reset() { for (auto *a : {&wall_ns, &inflate_ns, &seq_wait_ns, &queue_full_ns, &submit_ns, &slot_wait_ns, &index_wait_ns, &drain_ns, &comp_bytes, &text_bytes, &threads, &chunks}) a->store(0); }
+};
+VfFastqStats *vf_internal_fastq_stats(vf_ctx *c);
+
 // The exception barrier of the C ABI (include/vfind_hip.h: "no exceptions or panics cross the ABI"): every extern "C" entry
 // point runs its body inside vf_guard, so a std::bad_alloc or a length_error from a vector sized by a device-read value
 // comes back as an error code and a message, never as std::terminate in the host process - what lib.rs:317 does with a
@@ -58,5 +67,6 @@ struct vf_result {
     std::vector<uint8_t, VfNoInit<uint8_t>> keys;        // concatenated UTF-8 keys
     std::vector<uint64_t, VfNoInit<uint64_t>> offsets;   // rows + 1
     std::vector<uint64_t, VfNoInit<uint64_t>> counts;    // rows
+    uint64_t dup_rows = 0;                               // entries folded into another row (equal strings), vf_stats.dup_rows
 };
 

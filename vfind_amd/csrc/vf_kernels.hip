@@ -1857,8 +1857,9 @@ __device__ __forceinline__ void agg_flush(Agg &a, const CountLog &log, uint32_t 
 // a key only once the table had it, i.e. after that storm).  Entry = 16 dwords:
 //   { state, h1, h2, meta | slot, count, -, - | key[0..3] | key[4..7] }
 //   state 0 free, 1 claimed (key and tags written by the claiming lane right after the claim; slot not yet known),
-//   2 slot known.  Tags are written after the key words and a wave's LDS operations execute in order, so a reader that
-//   sees matching tags sees the whole key; an entry is never replaced; meta is never 0 (a counted key has a length).
+//   2 slot known.  The last tag word (meta) is release-stored after everything else of the entry and acquire-loaded first by
+//   readers (keycache_match), so a reader that sees it sees the whole key; an entry is never replaced; meta is never 0 (a
+//   counted key has a length).
 // Direct mapped by h1; keys of more than eight dwords are not cached.  Flushed at kernel end as (slot, count) pairs.
 #ifndef VF_KEYCACHE_SIZE
 #define VF_KEYCACHE_SIZE 256
@@ -1872,12 +1873,21 @@ __device__ __forceinline__ void keycache_init(KeyCache &kc) {
     }
 }
 __device__ __forceinline__ uint32_t keycache_index(uint32_t h1) { return ((h1 * 0x9E3779B1u) >> 16) & (uint32_t)(kKeyCacheSize - 1); }
+// Publication of an entry's key (C++ / HSA memory model, workgroup scope, LDS): the claiming lane writes the key words, the
+// slot word and two of the three tag words with plain stores and then RELEASE-stores the last tag word, `meta` (never 0; 0
+// until then - entries are never replaced); a reader ACQUIRE-loads `meta` first and looks at the other words only behind a
+// match.  Rounds 2-3 wrote tags after key words with plain volatile stores and leaned on one CU's LDS executing the DS
+// operations of different waves in arrival order - true of the hardware, not of the memory model (a false hit would count a
+// read against the wrong key's slot, silently).  On gfx950 the release costs one s_waitcnt lgkmcnt(0) in the claiming lane's
+// wave, once per entry; the acquire is the wait the compare needs anyway.
+__device__ __forceinline__ uint32_t keycache_meta_acquire(KeyCache &kc, uint32_t i) {
+    return __hip_atomic_load(reinterpret_cast<uint32_t *>(&kc.q[i][0]) + 3, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ bool keycache_match(KeyCache &kc, uint32_t i, uint32_t h1, uint32_t h2, uint32_t meta, const uint32_t (&kin)[kInlineDwords]) {
-    // volatile: the compiler keeps the LDS reads in program order (tags, then key words)
+    if (keycache_meta_acquire(kc, i) != meta) return false;
     const u32x4 t0 = *VF_LDS(u32x4, &kc.q[i][0]);
-    if (t0.x == 0u || t0.y != h1 || t0.z != h2 || t0.w != meta) return false;
     const u32x4 k0 = *VF_LDS(u32x4, &kc.q[i][2]), k1 = *VF_LDS(u32x4, &kc.q[i][3]);
-    const uint32_t diff = (k0.x ^ kin[0]) | (k0.y ^ kin[1]) | (k0.z ^ kin[2]) | (k0.w ^ kin[3]) |
+    const uint32_t diff = (t0.y ^ h1) | (t0.z ^ h2) | (k0.x ^ kin[0]) | (k0.y ^ kin[1]) | (k0.z ^ kin[2]) | (k0.w ^ kin[3]) |
                           (k1.x ^ kin[4]) | (k1.y ^ kin[5]) | (k1.z ^ kin[6]) | (k1.w ^ kin[7]);
     return diff == 0u;
 }
@@ -1893,11 +1903,12 @@ __device__ __forceinline__ int keycache_probe(KeyCache &kc, uint32_t h1, uint32_
         *VF_LDS(u32x4, &kc.q[i][2]) = u32x4{kin[0], kin[1], kin[2], kin[3]};
         *VF_LDS(u32x4, &kc.q[i][3]) = u32x4{kin[4], kin[5], kin[6], kin[7]};
         *VF_LDS(u32x4, &kc.q[i][1]) = u32x4{kNoSlot, 0u, 0u, 0u};
-        VF_LDS(uint32_t, st)[1] = h1; VF_LDS(uint32_t, st)[2] = h2; VF_LDS(uint32_t, st)[3] = meta;
+        VF_LDS(uint32_t, st)[1] = h1; VF_LDS(uint32_t, st)[2] = h2;
+        __hip_atomic_store(st + 3, meta, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         role = kCacheOwner;
     }
-    // (the lanes of this wave that lost the claim to a lane with the same key find the key written: same instruction
-    // stream, LDS operations in order)
+    // (the lanes of this wave that lost the claim to a lane with the same key find the key published: the release store
+    // above is earlier in the same instruction stream)
     if (can && role == kCacheNone && keycache_match(kc, i, h1, h2, meta, kin)) {
         atomicAdd(reinterpret_cast<uint32_t *>(&kc.q[i][1]) + 1, 1u);
         role = kCacheCounted;
@@ -1913,7 +1924,9 @@ __device__ __forceinline__ void keycache_publish(KeyCache &kc, uint32_t h1, uint
     volatile __attribute__((address_space(3))) uint32_t *st = VF_LDS(uint32_t, &kc.q[i][0]);
     if (st[0] != 1u || !keycache_match(kc, i, h1, h2, meta, kin)) return;
     VF_LDS(uint32_t, &kc.q[i][1])[0] = slot;
-    st[0] = 2u;
+    // (slot and state are read back only by keycache_flush, behind the workgroup barrier at kernel end; the release keeps
+    // the pair ordered for whoever reads them earlier)
+    __hip_atomic_store(reinterpret_cast<uint32_t *>(&kc.q[i][0]), 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // after the workgroup's last table access.  An entry with occurrences but no slot means its owner's insert failed: the
 // table or the arena is full, which the insert has flagged; flagged again here so that it cannot pass unseen.
@@ -2954,7 +2967,18 @@ __global__ __launch_bounds__(kBlock) void k_merge(Table t, const uint64_t *__res
         uint64_t ref = 0, cnt = 0;
         if (valid) { ref = refs[e]; cnt = counts[e]; }
         const uint32_t len = (uint32_t)(ref & 0xFFFFull), kind = (uint32_t)((ref >> 16) & 3ull);
-        table_add(t, bt, MemKey{arena + (ref >> 24), 1ull}, kind, len, cnt, valid);
+        // A table cleared by epoch stores letter keys with the epoch in their bytes' top bits and strips those bits on the way
+        // out: a byte-wise key that uses them (a multi-byte UTF-8 region out of a skip_translation context's export, a malformed
+        // peer blob) would come back corrupted, and a reader of its line would wait for ever for "written" dwords.  Such a key
+        // is refused, loudly (C_ERROR bit 5 -> VF_EINVAL), never stored.
+        bool storable = valid;
+        if (valid && t.key_tag != 0u && kind == kKindBytes) {
+            uint32_t high = 0;
+            const uint32_t nd = key_dwords(kind, len);
+            for (uint32_t d = 0; d < nd; ++d) high |= arena[(ref >> 24) + d] & kTagBits;
+            if (high) { storable = false; atomicOr((unsigned long long *)&t.counters[C_ERROR], 32ull); }
+        }
+        table_add(t, bt, MemKey{arena + (ref >> 24), 1ull}, kind, len, cnt, storable);
     }
     __syncthreads();
     block_table_end(bt, t);

@@ -224,7 +224,7 @@ hipError_t rebase_refs(hipStream_t s, const uint64_t *d_refs, uint64_t n, uint64
 // refs / counts / arena: an exported table in device memory (vf_table_export's blob); fills `out` (host vectors)
 int build_result_on_device(hipStream_t s, const uint64_t *d_refs, const uint64_t *d_counts, const uint32_t *d_arena, uint64_t n,
                            bool check_utf8, vf_result &out, std::string &err) {
-    out.keys.clear(); out.offsets.assign(1, 0); out.counts.clear();
+    out.keys.clear(); out.offsets.assign(1, 0); out.counts.clear(); out.dup_rows = 0;
     if (n == 0) return VF_OK;
     static const bool timing = getenv("VFIND_RESULT_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
@@ -284,6 +284,7 @@ int build_result_on_device(hipStream_t s, const uint64_t *d_refs, const uint64_t
     RS_TRY(hipMemcpyAsync(&g32, gid.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost, s));
     RS_TRY(hipStreamSynchronize(s));
     const uint64_t g = g32;
+    out.dup_rows = m - g;                                   // kept entries that shared their string with another one
     Dev gcount, grep, order, order2;
     RS_TRY(gcount.alloc(g * 8)); RS_TRY(grep.alloc(g * 4)); RS_TRY(order.alloc(g * 4)); RS_TRY(order2.alloc(g * 4));
     RS_TRY(hipMemsetAsync(gcount.p, 0, g * 8, s));

@@ -4,7 +4,7 @@ The hot path shards by reads with no data-path collective; the only exchange is 
 (key,count) table merge (the cross-GPU half of the reduce at src/lib.rs:292-306)."""
 from __future__ import annotations
 
-from typing import List, Tuple
+from typing import Tuple
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
@@ -12,36 +12,6 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     base, rem = divmod(n_items, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
-
-
-def allgather_blobs(send, nbytes: int, group=None) -> List[Tuple[object, int]]:
-    """All-gather variable-size byte blobs.
-
-    `send` is a uint8 tensor (any device) whose first `nbytes` bytes are this rank's blob.  Returns,
-    per rank, (uint8 tensor view, valid byte count).  Blobs are padded to the largest size (rounded
-    up to 256 B) so a single all_gather_into_tensor moves everything (one collective, large
-    messages: xGMI rings are per-link bound, so fewer/larger is better than per-peer sends)."""
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    # gloo (CPU tests, or a single-GPU rehearsal of the multi-rank path) moves the bytes through
-    # host memory; nccl (= RCCL) gathers device to device over xGMI
-    via_host = dist.get_backend(group) == "gloo" and send.device.type != "cpu"
-    wire = torch.device("cpu") if via_host else send.device
-    sizes = torch.zeros(world, dtype=torch.int64, device=wire)
-    sizes[rank] = nbytes
-    dist.all_reduce(sizes, group=group)
-    sizes_h = [int(x) for x in sizes.cpu().tolist()]
-    cap = (max(sizes_h) + 255) // 256 * 256
-    buf = torch.zeros(cap, dtype=torch.uint8, device=wire)
-    buf[:nbytes] = send[:nbytes].to(wire)
-    recv = torch.empty(world * cap, dtype=torch.uint8, device=wire)
-    dist.all_gather_into_tensor(recv, buf, group=group)
-    if via_host:
-        recv = recv.to(send.device)
-    return [(recv[r * cap:(r + 1) * cap], sizes_h[r]) for r in range(world)]
 
 
 def _padded(n: int) -> int:
@@ -54,20 +24,27 @@ def exchange_shares(engine, group=None, dst: int = 0):
     and nowhere else (every entry crosses the wire once, as in the library's own RCCL exchange), every owner clears its
     table and merges the buckets it holds, and a second all_to_all_single - all splits zero except towards `dst` - takes
     the owners' tables (disjoint key sets) to `dst`, which merges them.  Works on nccl (device buffers) and on gloo (the
-    CPU-side rehearsal: the bytes are staged through host memory)."""
+    CPU-side rehearsal: the bytes are staged through host memory).
+
+    `engine` is anything with the Engine methods used here (partition_sizes / partition_export / clear / merge_from /
+    export_size / export_to / wait_stream on raw addresses).  An engine with a `torch_device` attribute keeps its blobs on
+    that device - tests/test_distributed_cpu.py runs this function's split / offset arithmetic over gloo with a dict-backed
+    stand-in on CPU tensors, no GPU involved."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    dev = torch.device("cuda", engine.device)
-    via_host = dist.get_backend(group) == "gloo"
+    dev = getattr(engine, "torch_device", None) or torch.device("cuda", engine.device)
+    on_gpu = dev.type == "cuda"
+    via_host = dist.get_backend(group) == "gloo" and on_gpu
     wire = torch.device("cpu") if via_host else dev
 
     def lib_waits_for_torch():
         # buffers torch has just written go to the library only behind an event on torch's stream (vf_wait_stream); the
         # other direction needs nothing: vf_table_export / _merge return when the library's stream is done with the buffer
-        engine.wait_stream(torch.cuda.current_stream(dev).cuda_stream)
+        if on_gpu:
+            engine.wait_stream(torch.cuda.current_stream(dev).cuda_stream)
 
     def all_sizes(mine):                                         # [from][to], bytes
         t = torch.tensor(mine, dtype=torch.int64, device=wire)
