@@ -88,6 +88,7 @@ def other_config_leg(vfind_amd, synth, oracle, name, device, host_threads, n, n_
         eng.clear()
         eng.process_device(rows.data_ptr(), gen.row_dwords, lens.data_ptr(), n_parity)
         got = eng.finish_dict()
+        dup = int(eng.stats()["dup_rows"])
         data, offs = gen.ascii(0, n_parity, host_threads)
         tq = time.perf_counter()
         want = oracle.count((data, offs), ads, n_threads=host_threads)
@@ -102,7 +103,7 @@ def other_config_leg(vfind_amd, synth, oracle, name, device, host_threads, n, n_
                 "roofline_path": {"bound": "hbm", "achieved": round(gbps, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                   "frac": round(gbps / HBM_PEAK_GBPS, 6), "alg_bytes_per_read": b_alg(L)},
                 "alignments_per_read": round((st["dp_prefix"] + st["dp_suffix"]) / steps / n, 3),
-                "parity_full_table": True, "parity_reads": n_parity, "table_rows": len(got),
+                "parity_full_table": True, "parity_reads": n_parity, "table_rows": len(got), "dup_rows": dup,
                 "cpu_oracle_M_reads_per_s": round(n_parity / cpu_dt / 1e6, 3), "cpu_threads": host_threads}
     finally:
         eng.close()
@@ -169,27 +170,86 @@ def pcie_inclusive_leg(vfind_amd, gen, ads, n, L, device, slots, host_threads, r
         eng.close()
 
 
-def end_to_end_leg(vfind_amd, gen, ads, n_reads, device, slots):
-    """find_variants as a user calls it: gzip FASTQ file -> frame.  A multi-member file of the bench's own reads (level 1, binned
-    quality strings), timed with the reference's default n_threads = 3 and with all 16 threads of the box's share."""
+def end_to_end_leg(vfind_amd, oracle, gen, ads, n_reads, device, slots, host_threads, sample_reads=2_000_000):
+    """BASELINE configs[2] in shape - "2 x gzipped FASTQ, host decode / H2D overlap stressed" - as a find_variants caller gets it:
+    TWO multi-member gzip FASTQ files of the bench's own read model (R1 and R2 as two independent inputs: the reference has no
+    paired mode, lib.rs:220 takes one path) run into ONE context, then the frame.  Timed with the reference's default
+    n_threads = 3 and with all host threads of the box's share; the stage timers of vf_stats (host steady_clock) say where the
+    wall time goes; the CPU restatement (oracle.count_fastq: the reference's own shape, one reader + W workers + one reducer)
+    is timed beside it on a bounded sample file of the same stream, whose table the device must reproduce."""
     import tempfile
+    import zlib
     from benchlib import fastq
-    out = {"reads": n_reads, "members": 32}
+    half = n_reads // 2
+    members = max(8, half // 160_000)                      # ~ 50 MB of text a member
+    out = {"reads": 2 * half, "files": 2, "members_per_file": members}
     with tempfile.TemporaryDirectory() as d:
-        path = os.path.join(d, "bench.fq.gz")
+        paths = [os.path.join(d, "bench_R1.fq.gz"), os.path.join(d, "bench_R2.fq.gz")]
+        sample = os.path.join(d, "sample.fq.gz")
         t0 = time.perf_counter()
-        out["file_MB"] = round(fastq.write_fastq_gz(path, gen, n_reads, members=32, threads=16) / 1e6, 1)
+        size = sum(fastq.write_fastq_gz(p, gen, half, members=members, threads=host_threads, first=k * half) for k, p in enumerate(paths))
+        fastq.write_fastq_gz(sample, gen, sample_reads, members=16, threads=host_threads)
+        out["file_MB"] = round(size / 1e6, 1)
         out["write_s"] = round(time.perf_counter() - t0, 1)
-        for nt in (3, 16):
+        # zlib 1.2.11 (through Python's binding) on the first member of the same file, one thread: what the library's own decoder
+        # (vf_inflate.cpp) is read against
+        raw = open(paths[0], "rb").read(1 << 28)
+        tz = time.perf_counter()
+        dz = zlib.decompressobj(31)
+        text = dz.decompress(raw)
+        out["zlib_MBps_of_text_per_thread"] = round(len(text) / (time.perf_counter() - tz) / 1e6, 1)
+        del raw, text, dz
+        sample_want = None
+        for nt in (3, host_threads):
             with vfind_amd.Engine(ads, device=device, table_slots=slots, arena_bytes=1 << 30, n_threads=nt, queue_len=4) as e:
-                e.run_fastq(path)                          # first call allocates staging and workspaces
+                e.run_fastq(sample)                        # first call allocates staging and workspaces; its table is the parity sample
+                got = e.finish_dict()
+                if sample_want is None:
+                    tq = time.perf_counter()
+                    sample_want = oracle.count_fastq(sample, ads, n_threads=host_threads)
+                    t_all = time.perf_counter() - tq
+                    tq = time.perf_counter()
+                    oracle.count_fastq(sample, ads, n_threads=3)
+                    t_3 = time.perf_counter() - tq
+                    out["cpu_baseline"] = {"kind": "port", "unit": "M reads/s", "sample": f"a {sample_reads}-read file of the same stream (16 members)",
+                                           "workers_3": round(sample_reads / t_3 / 1e6, 3), f"workers_{host_threads}": round(sample_reads / t_all / 1e6, 3),
+                                           "what": "oracle.count_fastq: zlib reader thread -> W workers -> one serial reducer (the reference's shape, lib.rs:233-234, 271-306)"}
+                if got != sample_want:
+                    raise SystemExit("PARITY FAILED (end to end): vf_run_fastq table differs from oracle.count_fastq on the sample file")
                 e.clear()
+                e.reset_stats()
                 t0 = time.perf_counter()
-                e.run_fastq(path)
+                for p in paths:
+                    e.run_fastq(p)
+                t_run = time.perf_counter() - t0
                 frame = e.finish_arrays()
                 dt = time.perf_counter() - t0
-                out[f"n_threads_{nt}"] = {"value": round(n_reads / dt / 1e6, 2), "unit": "M reads/s", "seconds": round(dt, 3), "rows": len(frame[2])}
-    out["what"] = "vf_run_fastq + vf_finish on a gzip FASTQ of the same read model (host inflate bound; never `value`)"
+                st = e.stats()
+                thr = max(int(st["fq_inflate_threads"]), 1)
+                leg = {"value": round(2 * half / dt / 1e6, 2), "unit": "M reads/s", "seconds": round(dt, 3), "rows": len(frame[2]), "dup_rows": int(st["dup_rows"]),
+                       "stages_ms": {"wall_run_fastq": round(st["fq_wall_ms"], 1), "finish": round((dt - t_run) * 1e3, 1),
+                                     "inflate_thread_sum": round(st["fq_inflate_ms"], 1), "inflate_per_thread": round(st["fq_inflate_ms"] / thr, 1),
+                                     "sequencer_waits_for_text": round(st["fq_seq_wait_ms"], 1), "sequencer_waits_for_queue": round(st["fq_queue_full_ms"], 1),
+                                     "submit_thread_sum": round(st["fq_submit_ms"], 1), "of_it_waiting_for_a_slot": round(st["fq_slot_wait_ms"], 1),
+                                     "of_it_waiting_for_the_line_index": round(st["fq_index_wait_ms"], 1), "final_drain": round(st["fq_drain_ms"], 1)},
+                       "inflate_threads": thr, "chunks": int(st["fq_chunks"]),
+                       "text_MB": round(st["fq_text_bytes"] / 1e6, 1),
+                       "inflate_MBps_of_text_per_thread": round(st["fq_text_bytes"] / max(st["fq_inflate_ms"], 1e-3) / 1e3, 1),
+                       "text_GBps_overall": round(st["fq_text_bytes"] / dt / 1e9, 2)}
+                # device time of the same path per stage: the sample file again with every launch bracketed (not in `value`)
+                e.clear()
+                e.reset_stats()
+                e.set_profiling(1)
+                e.run_fastq(sample)
+                e.set_profiling(0)
+                sd = e.stats()
+                leg["device_ms_per_M_reads"] = {k: round(sd[f] / (sample_reads / 1e6), 3) for k, f in (
+                    ("h2d_text", "ms_h2d"), ("line_index_frame_pack", "ms_frame"), ("scan", "ms_scan"), ("filter", "ms_filter"), ("dp", "ms_dp_window"),
+                    ("finish", "ms_finish"), ("count_log", "ms_count_log"), ("generic", "ms_generic"))}
+                out[f"n_threads_{nt}"] = leg
+    out["parity_sample_file"] = True
+    out["what"] = ("vf_run_fastq x 2 files + vf_finish on gzip FASTQ of the same read model (never `value`); stages: host steady_clock timers of vf_stats "
+                   "(thread sums where several threads work), device_ms: HIP events around every launch in a separate pass over the sample file")
     return out
 
 
@@ -222,7 +282,7 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--table-slots", type=int, default=0, help="count-table slots (0 = 2x the variant library, power of two)")
     ap.add_argument("--no-extras", action="store_true", help="skip the legs beside the headline: result build, PCIe-inclusive, end-to-end FASTQ, tie-sensitive fraction")
-    ap.add_argument("--e2e-reads", type=int, default=2_000_000, help="reads of the gzip FASTQ file of the end-to-end leg")
+    ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the two gzip FASTQ files of the end-to-end leg (BASELINE configs[2] in shape)")
     ap.add_argument("--other-config-reads", type=int, default=8_000_000, help="resident reads per step of each of the other BASELINE shapes (extras)")
     ap.add_argument("--other-config-parity-reads", type=int, default=2_000_000, help="reads of those shapes whose whole table is compared with the CPU oracle")
     ap.add_argument("--merge-transport", default="auto", choices=["auto", "rccl", "torch"],
@@ -430,10 +490,12 @@ def main():
     # ---- full-size parity: the table left by the last timed step (resident packed path, all n reads)
     # against the oracle's table of the same reads, when the CPU baseline sample covered them all
     parity_full = None
+    dup_rows_full = None
     if rank == 0 and oracle_full is not None and oracle_full_n == n and not args.no_parity and not keep_table:
         parity_full = eng.finish_dict() == oracle_full
         if not parity_full:
             raise SystemExit("PARITY FAILED at full size: device table differs from the CPU oracle")
+        dup_rows_full = int(eng.stats()["dup_rows"])
     oracle_full = None
 
     # ---- beside the headline (rank 0 at N = 1; none of it is `value`) ---------------------------------------------
@@ -446,7 +508,8 @@ def main():
                             "what": "vf_finish: table export, strings expanded + duplicates summed + rows sorted (count desc, sequence asc) on the device, one copy back"}
         del keys, offs, cnts
         extras["pcie_inclusive"] = pcie_inclusive_leg(vfind_amd, gen, ads, n, L, local_rank, slots, host_threads)
-        extras["end_to_end"] = end_to_end_leg(vfind_amd, gen, ads, args.e2e_reads, local_rank, slots)
+        from oracle import oracle as _oracle_e2e            # checker + CPU baseline of the leg; outside every timed device region
+        extras["end_to_end"] = end_to_end_leg(vfind_amd, _oracle_e2e, gen, ads, args.e2e_reads, local_rank, slots, host_threads)
         if not args.no_parity and not args.no_cpu_baseline:
             # BASELINE.json configs[3] and configs[4] in shape (their read counts are 8-GPU jobs), each with its whole table checked
             from oracle import oracle as _oracle
@@ -576,7 +639,7 @@ def main():
                          "valu_all_reads_aligned_M_reads_per_s": round(1024 * 2.1e9 / 2.3 * 64 / (2 * L * args.adapter_len * 11.45) / 1e6, 1),
                          "pcie_gen5_x16_M_reads_per_s": round(63e9 / ((2 * L + 7) // 8 + 2) / 1e6, 1)},
             "cpu_baseline": cpu,
-            "parity_gate": parity, "parity_full_size": parity_full, "table_cleared_each_step": not keep_table,
+            "parity_gate": parity, "parity_full_size": parity_full, "dup_rows_full_size": dup_rows_full, "table_cleared_each_step": not keep_table,
             "merge_ms": None if merge_ms is None else round(merge_ms, 3), "merge_error": merge_error,
             "merge_transport": None if world == 1 else {"rccl": "rccl (vf_table_allreduce)"}.get(getattr(eng, "last_merge_transport", args.merge_transport), getattr(eng, "last_merge_transport", args.merge_transport)),
             "value_spread": spread, "other_configs": extras.get("other_configs"),

@@ -8,8 +8,8 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 
-def write_fastq_gz(path: str, gen, n_reads: int, members: int = 16, level: int = 1, threads: int = 16, seed: int = 99) -> int:
-    """n_reads of the generator as a multi-member gzip FASTQ (members compressed in parallel); returns the file size"""
+def write_fastq_gz(path: str, gen, n_reads: int, members: int = 16, level: int = 1, threads: int = 16, seed: int = 99, first: int = 0) -> int:
+    """reads [first, first + n_reads) of the generator as a multi-member gzip FASTQ (members compressed in parallel); returns the file size"""
     per = (n_reads + members - 1) // members
     L = gen.read_len
 
@@ -17,14 +17,14 @@ def write_fastq_gz(path: str, gen, n_reads: int, members: int = 16, level: int =
         lo, hi = m * per, min(n_reads, (m + 1) * per)
         if lo >= hi:
             return b""
-        b, _ = gen.ascii(lo, hi - lo, 2)
+        b, _ = gen.ascii(first + lo, hi - lo, 2)
         seqs = b.reshape(-1, L)
         n = hi - lo
         w = 12 + L + 3 + L + 1
         rec = np.empty((n, w), np.uint8)
         rec[:, 0] = ord("@")
         rec[:, 1] = ord("r")
-        idx = lo + np.arange(n, dtype=np.int64)
+        idx = first + lo + np.arange(n, dtype=np.int64)
         for d in range(9):
             rec[:, 2 + d] = ord("0") + (idx // 10 ** (8 - d)) % 10
         rec[:, 11] = ord("\n")

@@ -291,6 +291,60 @@ def test_banded_class_single_edit_tasks():
         _check_counts(rd, AD20)
 
 
+def test_hamming_certified_band_two_substitution_tasks():
+    """Round 4: a single-cluster task whose cluster's centre diagonal carries the adapter with h >= 2 substitutions takes a band of
+    (hi - lo) + 2 kq + 1 diagonals instead of a 64-column window (hamming_band_class in the Myers pass).  EVERY
+    pair of substituted adapter positions, for both adapters, with the adapter at the read start (band left of column 0), at
+    the read end (last-column cells), behind short and long flanks, overhanging either end, next to a worse second copy;
+    three and four substitutions, a substitution pair next to an indel (no certificate: the window classes), several scoring
+    schemes - spans against the oracle's full DP"""
+    rng = np.random.default_rng(20261005)
+    R = lambda k: synth.rand_seq(rng, k).decode()
+    other = lambda c: "ACGT"[("ACGT".index(c) + 1 + int(rng.integers(0, 3))) % 4]
+
+    def subs(ad, pos):
+        a = list(ad)
+        for p in pos:
+            a[p] = other(a[p])
+        return "".join(a)
+    for ads in (AD20, ("GATCGGAAGAGCACACGTCTGAACTCCAGT", "AGATCGGAAGAGCGTCGTGTAGGGAAAGAG"), ("ACGGTCATGCA", "TTGCAAGCGTAC")):
+        P, S = ads
+        reads = []
+        for ad, is_p in ((P, True), (S, False)):
+            m = len(ad)
+            oth = S if is_p else P
+            k = 0
+            for i in range(m):
+                for j in range(i + 1, m):
+                    e = subs(ad, (i, j))
+                    flank, tail = (0, 1, 2, 5, 11, 40)[k % 6], (0, 1, 3, 6, 2, 0)[(k // 6) % 6]
+                    k += 1
+                    body = R(flank) + e + R(30 + tail) + oth if is_p else oth + R(33) + R(flank) + e + R(tail)
+                    reads.append(body)
+            for t in range(60):                                                                   # three and four substitutions, cut copies
+                pos = sorted(rng.choice(m, size=3 + t % 2, replace=False).tolist())
+                e = subs(ad, pos)
+                reads.append(R(t % 7) + e + R(35) + oth if is_p else oth + R(35) + e + R(t % 5))
+                e2 = subs(ad, pos[:2])
+                reads.append(e2[1 + t % 3:] + R(40) + oth if is_p else oth + R(40) + e2[: m - 1 - t % 3])      # two substitutions + overhang
+                q = int(rng.integers(1, m - 1))
+                e3 = e2[:q] + (R(1) if t % 2 else "") + e2[q + (0 if t % 2 else 1):]               # + one inserted / deleted base
+                reads.append(R(3) + e3 + R(35) + oth if is_p else oth + R(35) + e3 + R(2))
+                reads.append(R(2) + e2 + R(t % 4) + subs(ad, pos) + R(30) + oth if is_p else oth + R(30) + subs(ad, pos) + R(t % 4) + e2)   # second copy close by
+        reads = [r.encode() for r in reads]
+        for kw in (dict(), dict(accept_prefix_alignment=0.6, accept_suffix_alignment=0.7),
+                   dict(match_score=2, mismatch_score=-1, gap_open_penalty=3, gap_extend_penalty=1, accept_prefix_alignment=0.6, accept_suffix_alignment=0.6),
+                   dict(match_score=5, mismatch_score=-1, gap_open_penalty=5, gap_extend_penalty=2, accept_prefix_alignment=0.6, accept_suffix_alignment=0.6),
+                   dict(match_score=4, mismatch_score=-4, gap_open_penalty=8, gap_extend_penalty=4, accept_prefix_alignment=0.5, accept_suffix_alignment=0.5)):
+            _check_spans(reads, ads, **kw)
+        _check_counts(reads, ads)
+    # a library with 15 % substitutions (the cfg-4 shape): most accepted tasks carry two substitutions; every read length mod 16
+    for seed, L in ((401, 150), (402, 151), (403, 157), (404, 160), (405, 98)):
+        rd = synth.make_reads(seed, 4000, AD20, L=L, sub=0.15, indel=0.0, flank_max=9, vary_len=True)
+        _check_spans(rd, AD20)
+        _check_counts(rd, AD20)
+
+
 @pytest.mark.parametrize("name,kw", [
     ("cfg2", dict(seed=0x5EED0002, read_len=150, m=20, sub_rate=0.005, indel_rate=0.0005)),
     ("cfg4", dict(seed=0x5EED0004, read_len=150, m=20, sub_rate=0.15, indel_rate=0.0)),

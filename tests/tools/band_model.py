@@ -365,6 +365,130 @@ def wide_case(rng, stats=None):
     return good
 
 
+# ---- the Hamming certificate (round 4): banded classes for single-cluster tasks with two or more substitutions ---------------
+# The adapter laid on the cluster's centre diagonal(s) differs from the read in h bases: an ungapped alignment of score
+# match*m - h*(match - mismatch), hence S* >= T'' = max(T, that) and every optimal alignment has at most
+# kq = max_unit_errors(T'') unit edits.  End columns of optimal alignments lie kerr - kq inside the cluster, their cells on
+# [lo - m - kq, hi - m + kq] (vf_kernels.hip, hamming_band_class / myers_classify).
+def hamming_decision(ad, read, T, kerr, match, mismatch, gopen, gext, k_lo=None, kq_shift=0):
+    """the Myers pass's class decision for one task as myers_classify makes it, restricted to what the certificate adds:
+    returns None (the certificate does not apply / the task is class 0 by the d <= 1 rule already) or (band width, av, h, kq)"""
+    m, n = len(ad), len(read)
+    D = myers_last_row(ad, read)
+    det = [j for j in range(1, n + 1) if D[j] <= kerr]
+    if not det:
+        return None
+    ncl, c = clusters(det, m + kerr)
+    if ncl != 1:
+        return None
+    jmin, jmax = c[0], c[1]
+    own = 4 * (n // 4)
+    dmin = min(D[1: own + 1]) if own else m
+    if k_lo is not None and dmin <= 1:                       # class 0 by the tightened bound of a d <= 1 column (one_case covers it)
+        dl = kerr - k_lo
+        lo = jmin + dl if jmin > 1 else 1
+        hi = jmax - dl if jmax < n else n
+        if hi >= lo and hi - lo + 2 * k_lo + 1 <= KBAND:
+            return None
+    hmin = None
+    for e in (0, 1):
+        jc = (jmin + jmax + e) >> 1
+        d = jc - m
+        if d < 0 or jc > n:
+            continue
+        h = sum(a != b for a, b in zip(ad, read[d:d + m]))
+        hmin = h if hmin is None else min(hmin, h)
+    if hmin is None or not (1 <= hmin <= 7) or hmin > kerr:
+        return None
+    T2 = max(T, match * m - hmin * (match - mismatch))
+    kq = max_unit_errors(T2, m, match, mismatch, gopen, gext)
+    if kq is None or not (1 <= kq < kerr):
+        return None
+    kq_used = kq - kq_shift                                  # (kq_shift = 1: the test that shows the model bites)
+    if kq_used < 1:
+        return None
+    dl = kerr - kq_used
+    lo = jmin + dl if jmin > 1 else 1
+    hi = jmax - dl if jmax < n else n
+    if hi < lo:
+        return None
+    width = hi - lo + 2 * kq_used + 1
+    if width <= KBAND:
+        return KBAND, lo - m - kq_used, hmin, kq
+    if width <= KBAND_W:
+        return KBAND_W, lo - m - kq_used, hmin, kq
+    return None
+
+
+def hamming_case(rng, stats=None, kq_shift=0):
+    """one random task; None = the certificate does not classify it, else True/False = banded DP == full-matrix DP"""
+    match = rng.choice([1, 2, 3, 3, 3, 4, 5])
+    mismatch = rng.choice([-4, -3, -2, -2, -2, -1, 0])
+    gopen = rng.choice([0, 2, 3, 5, 5, 5, 8])
+    gext = rng.choice([1, 2, 2, 2, 3, 4])
+    m = rng.randint(8, 32)
+    acc = rng.choice([0.5, 0.6, 0.7, 0.75, 0.75, 0.75, 0.8])
+    T = int(acc * match * m // 1) + 1
+    ad = [rng.randrange(4) for _ in range(m)]
+    if rng.random() < 0.1:                                   # repetitive adapters: shifted diagonals look alike
+        u = [rng.randrange(4) for _ in range(rng.randint(1, 4))]
+        ad = (u * m)[:m]
+        for _ in range(rng.randint(0, 3)):
+            ad[rng.randrange(m)] = rng.randrange(4)
+    cp = list(ad)
+    for _ in range(rng.choice([2, 2, 2, 2, 3, 3, 4, 5])):
+        t = rng.random()
+        p = rng.randrange(len(cp))
+        if t < 0.82:
+            cp[p] = (cp[p] + rng.randint(1, 3)) % 4
+        elif t < 0.91:
+            cp.insert(p, rng.randrange(4))
+        elif len(cp) > 2:
+            del cp[p]
+    flank = [rng.randrange(4) for _ in range(rng.choice([0, 0, 1, 2, 3, 5, 9, 17, 40]))]
+    tail = [rng.randrange(4) for _ in range(rng.choice([0, 0, 1, 2, 3, 7, 20, 60]))]
+    read = flank + cp + tail
+    if rng.random() < 0.2:
+        read = read[rng.randint(1, 4):]
+    if rng.random() < 0.2:
+        read = read[: len(read) - rng.randint(1, 4)]
+    if rng.random() < 0.08:                                  # a second, damaged copy close by: one cluster, two candidates
+        cp2 = list(ad)
+        for _ in range(rng.randint(1, 4)):
+            cp2[rng.randrange(m)] = rng.randrange(4)
+        read = read + [rng.randrange(4) for _ in range(rng.choice([0, 1, 2, 4]))] + cp2
+    n = len(read)
+    if n == 0 or n > 640:
+        return None
+    kerr = max_unit_errors(T, m, match, mismatch, gopen, gext)
+    if kerr is None or kerr < 2 or m + kerr > 48:
+        return None
+    c_max = max(match, match - mismatch, match + max(gopen, gext))
+    k_lo = max_unit_errors(max(T, match * m - c_max), m, match, mismatch, gopen, gext)
+    if k_lo is None or not (1 <= k_lo < kerr):
+        k_lo = None
+    got = hamming_decision(ad, read, T, kerr, match, mismatch, gopen, gext, k_lo, kq_shift)
+    if got is None:
+        return None
+    kband, av, h, kq = got
+    letters = b"ACGT"
+    qb = bytes(letters[x] for x in ad)
+    rb = bytes(letters[x] for x in read)
+    if rb.find(qb) >= 0:
+        return None                                          # an exact copy: no alignment task exists
+    fs, fl, _, _ = pyref.sg_stats_py(qb, rb, match, mismatch, gopen, gext)
+    bs, bl = banded(ad, read, av, match, mismatch, gopen, gext, kband)
+    ok_full, ok_band = fs >= T, bs >= T
+    good = ok_full == ok_band and (not ok_full or (fs == bs and fl == bl))
+    if stats is not None:
+        stats[(kband, h)] = stats.get((kband, h), 0) + 1
+        stats["accepted" if ok_full else "rejected"] = stats.get("accepted" if ok_full else "rejected", 0) + 1
+    if not good:
+        print("MISMATCH (Hamming certificate)", dict(match=match, mismatch=mismatch, gopen=gopen, gext=gext, T=T, kerr=kerr, h=h, kq=kq, av=av, kband=kband),
+              qb, rb, "full", (fs, fl), "band", (bs, bl))
+    return good
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -385,7 +509,16 @@ def main():
         ranb += 1
         badb += not g
     print(f"{ranb} block-filter tasks ({stats}), {badb} mismatches")
-    return 1 if bad or badb else 0
+    ranh = badh = 0
+    hstats = {}
+    while ranh < cases:
+        g = hamming_case(rng, hstats)
+        if g is None:
+            continue
+        ranh += 1
+        badh += not g
+    print(f"{ranh} Hamming-certified tasks ({dict(sorted((str(k), v) for k, v in hstats.items()))}), {badh} mismatches")
+    return 1 if bad or badb or badh else 0
 
 
 if __name__ == "__main__":

@@ -45,6 +45,10 @@ struct DpParams {
     // nblk = 0: off (no tightened bound, a block shorter than 5 bases, or more than 4 blocks)
     uint32_t nblk;
     uint32_t blk_off[4], blk_len[4];
+    // Hamming certificate (hamming_band_class): kerr_h[h], h = 1..7 = the unit-edit bound of OPTIMAL alignments of a task that
+    // has a diagonal at Hamming distance h (max_unit_errors of max(T, match*m - h*(match - mismatch))), -1 where that is no
+    // tighter than kerr; kerr_h[0] = 1 if any entry is set (0 = certificate off)
+    int32_t kerr_h[8];
 };
 
 struct ScanParams {
@@ -155,7 +159,9 @@ uint64_t count_log_entries_max(uint64_t n_reads, uint32_t *grid_max);           
 
 // ---- launchers (vf_kernels.hip) ---------------------------------------------------------------
 struct BatchLists {        // per in-flight batch; lists are segmented per workgroup of k_scan
-    uint32_t *listP, *listS;          // DP tasks per adapter (grid*seg entries each)
+    const uint32_t *rows;             // the batch itself: the filter and DP stages gather their tasks' rows and lengths from it
+    const uint16_t *lens;
+    uint32_t *listP, *listS;          // DP tasks per adapter (grid*seg entries each): read index | suffix-pending flag << 31 (vf_kernels.hip, "Task entries")
     uint32_t *listW[4], *winW[4];     // filter output by class: 0 banded (+ first diagonal + kBandBias), 1..3 windowed (+ window a | b<<16)
     uint32_t *winW2;                  // second window of class-3 (two-window) tasks
     uint32_t *listF;                  // filter output: tasks only the full-width DP can take
@@ -179,14 +185,11 @@ void scan_geometry(uint64_t n, int W, uint32_t *grid, uint32_t *seg);
 uint64_t scan_list_entries(uint64_t n);           // list entries a batch of n reads needs at any row width
 hipError_t launch_scan(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n,
                        const ScanParams &sp, short2 *spans, BatchLists bl);
-hipError_t launch_bmfilter(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
-                           BatchLists bl, uint64_t *counters);
-hipError_t launch_filter(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
-                         short2 *spans, BatchLists bl, uint64_t *counters);
-hipError_t launch_dp_classes(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
-                             short2 *spans, BatchLists bl, uint64_t *counters);
-hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
-                     short2 *spans, BatchLists bl, uint64_t *counters);
+// (rows and lengths of the batch: bl.rows, bl.lens)
+hipError_t launch_bmfilter(hipStream_t s, int W, const DpParams &dp, short2 *spans, BatchLists bl, uint64_t *counters);
+hipError_t launch_filter(hipStream_t s, int W, const DpParams &dp, short2 *spans, BatchLists bl, uint64_t *counters);
+hipError_t launch_dp_classes(hipStream_t s, int W, const DpParams &dp, short2 *spans, BatchLists bl, uint64_t *counters);
+hipError_t launch_dp(hipStream_t s, int W, const DpParams &dp, short2 *spans, BatchLists bl, uint64_t *counters);
 // k_finish, then the kernels that apply its count log (same n, same table, same log, same stream)
 hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n,
                          const short2 *spans, bool skip_translation, Table t, CountLog log);

@@ -139,7 +139,7 @@ struct Workspace {               // device scratch of one in-flight batch
         l.cap_total = log_one.cap;
         return l;
     }
-    int ensure(size_t n) {
+    int ensure(size_t n, int /*W*/) {
         int rc;
         const size_t e = (size_t)scan_list_entries(n);
         if ((rc = spans.ensure(n))) return rc;
@@ -380,6 +380,16 @@ static void fill_dp(DpParams &d, const std::string &ad, int64_t T, const vf_ctx 
             o += ln;
         }
         if (shortest >= 5) d.nblk = nb;                 // shorter blocks turn up by chance too often to be worth the pass
+    }
+    // Hamming certificate: a diagonal on which the adapter differs from the read in h bases is an alignment of score
+    // match*m - h*(match - mismatch): the optimum is at least that, and optimal alignments have at most kerr_h[h] unit edits
+    for (int h = 0; h < 8; ++h) d.kerr_h[h] = h ? -1 : 0;
+    if (d.kerr >= 2 && d.kerr != INT32_MAX) {
+        for (int h = 1; h < 8 && h <= d.kerr; ++h) {
+            const int64_t T_h = std::max<int64_t>(T, (int64_t)c.match * (int64_t)ad.size() - (int64_t)h * ((int64_t)c.match - c.mismatch));
+            const int32_t k_h = max_unit_errors(T_h, ad.size(), c.match, c.mismatch, c.gopen, c.gext);
+            if (k_h >= 1 && k_h < d.kerr) { d.kerr_h[h] = k_h; d.kerr_h[0] = 1; }
+        }
     }
     const uint32_t up = 32u - d.m;                     // d.m in 1..32
     for (int q = 0; q < 4; ++q) d.eq_top[q] = up ? ((d.eq[q] << up) | ((1u << up) - 1u)) : d.eq[q];
@@ -799,13 +809,14 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
                       const uint16_t *d_lens, uint64_t n, short2 *d_spans, bool count, uint64_t *h_entries) {
     if (n == 0) return VF_OK;
     if (count) c->part_world = 0;
-    if (n > 0xFFFFFFF0ull) return fail(VF_EINVAL, "batch too large (max 2^32-16 reads per submission)");
+    if (n > 0x80000000ull) return fail(VF_EINVAL, "batch too large (max 2^31 reads per submission)");
     if (count) { const int lrc = ws.ensure_log(n, c->main_stream); if (lrc) return lrc; }
     // every third batch: an odd period, so that the sampled batches alternate between the two batch lanes (every fourth sat on
     // one lane, always in the same phase against the other lane's k_finish: k_scan 0.515 ms against 0.43-0.47 over all launches)
     const int pmode = c->profiling.load();
     const bool psample = pmode == 3 && c->prof_batch.fetch_add(1) % 3u == 0u;
     BatchLists bl{};
+    bl.rows = d_rows; bl.lens = d_lens;
     bl.listP = ws.listP.p; bl.listS = ws.listS.p; bl.listF = ws.listF.p;
     bl.cntP = ws.cnt.p; bl.cntS = ws.cnt.p + kMaxGrid; bl.cntF = ws.cnt.p + 2 * kMaxGrid;
     bl.winW2 = ws.winW2.p;
@@ -829,13 +840,13 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
         if (c->filter_on) {
             {
                 Timed t(c, st, K_FILTER, pmode, psample);
-                if (dp.nblk != 0 && c->block_filter) HIP_TRY(launch_bmfilter(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters));
-                else HIP_TRY(launch_filter(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters));
+                if (dp.nblk != 0 && c->block_filter) HIP_TRY(launch_bmfilter(st, W, dp, d_spans, bl, c->tab.counters));
+                else HIP_TRY(launch_filter(st, W, dp, d_spans, bl, c->tab.counters));
             }
-            { Timed t(c, st, K_DPW, pmode, psample); HIP_TRY(launch_dp_classes(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters)); }
+            { Timed t(c, st, K_DPW, pmode, psample); HIP_TRY(launch_dp_classes(st, W, dp, d_spans, bl, c->tab.counters)); }
         } else {
             Timed t(c, st, K_DPREST, pmode, psample);
-            HIP_TRY(launch_dp(st, W, d_rows, d_lens, dp, d_spans, bl, c->tab.counters));
+            HIP_TRY(launch_dp(st, W, dp, d_spans, bl, c->tab.counters));
         }
     }
     Table tab = c->tab;
@@ -1019,7 +1030,7 @@ static int submit_chunk(vf_ctx *c, const uint8_t *base, const ReadRef *reads, ui
     if (nf) {
         if ((rc = s->d_rows.ensure((size_t)nf * W))) return rc;
         if ((rc = s->d_lens.ensure(nf))) return rc;
-        if ((rc = s->ws.ensure(nf))) return rc;
+        if ((rc = s->ws.ensure(nf, W))) return rc;
         HIP_TRY(hipMemcpyAsync(s->d_rows.p, s->h_rows.p, (size_t)nf * W * 4, hipMemcpyHostToDevice, s->stream));
         HIP_TRY(hipMemcpyAsync(s->d_lens.p, s->h_lens.p, nf * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
         if ((rc = run_packed(c, s->stream, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, nf, s->ws.spans.p, !spans_mode, s->h_entries.p))) return rc;
@@ -1134,7 +1145,7 @@ static int vf_submit_packed_impl(vf_ctx *c, const uint32_t *rows, uint32_t W, co
         }
         if ((rc = s->d_rows.ensure((size_t)m * W))) return rc;
         if ((rc = s->d_lens.ensure(m))) return rc;
-        if ((rc = s->ws.ensure(m))) return rc;
+        if ((rc = s->ws.ensure(m, (int)W))) return rc;
         HIP_TRY(hipMemcpyAsync(s->d_rows.p, s->h_rows.p, (size_t)m * W * 4, hipMemcpyHostToDevice, s->stream));
         HIP_TRY(hipMemcpyAsync(s->d_lens.p, s->h_lens.p, m * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
         if ((rc = run_packed(c, s->stream, s->index, s->ws, s->d_rows.p, (int)W, s->d_lens.p, m, s->ws.spans.p, true, s->h_entries.p))) return rc;
@@ -1224,7 +1235,7 @@ static int vf_batch_submit_impl(vf_ctx *c, vf_batch *b, uint64_t n) {
     if ((rc = reserve_capacity(c, ticket, n, need))) return rc;
     const double t1 = dbg_t ? now() : 0;
     std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
-    if ((rc = s->d_rows.ensure((size_t)n * W)) || (rc = s->d_lens.ensure(n)) || (rc = s->ws.ensure(n))) return rc;
+    if ((rc = s->d_rows.ensure((size_t)n * W)) || (rc = s->d_lens.ensure(n)) || (rc = s->ws.ensure(n, (int)W))) return rc;
     const double t2 = dbg_t ? now() : 0;
     HIP_TRY(hipMemcpyAsync(s->d_rows.p, s->h_rows.p, (size_t)n * W * 4, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->d_lens.p, s->h_lens.p, n * sizeof(uint16_t), hipMemcpyHostToDevice, s->stream));
@@ -1253,7 +1264,8 @@ static int vf_process_device_packed_impl(vf_ctx *c, const void *d_rows, uint32_t
     // A resident batch may be cut into pieces that go down the batch lanes one after the other: a piece's rows are read by
     // k_scan, gathered from by the filter and DP kernels and streamed again by k_finish - pieces small enough for the rows of
     // the pieces in flight (and the table) to stay in the 256 MiB Infinity Cache make every visit after the first an on-die hit.
-    const uint64_t piece = res_split_reads();
+    uint64_t piece = res_split_reads();
+    if (piece == 0 && n > (1ull << 30)) piece = 1ull << 30;          // (a launch set takes at most 2^31 reads: 31-bit task entries)
     if (piece == 0 || n <= piece + piece / 2) return process_device_piece(c, (const uint32_t *)d_rows, W, (const uint16_t *)d_lens, n, (short2 *)d_spans);
     const uint64_t k = (n + piece - 1) / piece, each = ((n + k - 1) / k + 255) & ~255ull;      // equal pieces, whole workgroups
     for (uint64_t at = 0; at < n; at += each) {
@@ -1270,7 +1282,7 @@ static int process_device_piece(vf_ctx *c, const uint32_t *d_rows, uint32_t W, c
         if ((rc = table_grow_if_needed(c, *L.h_entries.p))) return rc;
     }
     std::shared_lock<std::shared_mutex> table_lock(c->table_mu);
-    if ((rc = L.ws.ensure(n))) return rc;
+    if ((rc = L.ws.ensure(n, (int)W))) return rc;
     short2 *spans = d_spans ? d_spans : L.ws.spans.p;
     if ((rc = run_packed(c, L.stream, L.chunk_row, L.ws, d_rows, (int)W, d_lens, n, spans, true, L.h_entries.p))) return rc;
     HIP_TRY(hipEventRecord(L.done, L.stream));
@@ -2223,7 +2235,7 @@ int vf_internal_submit_text(vf_ctx *c, const TextSpan *spans, size_t n_spans, bo
     if (W == 0) W = 40;
     if ((rc = s->d_rows.ensure((size_t)n * W))) return rc;
     if ((rc = s->d_lens.ensure(n))) return rc;
-    if ((rc = s->ws.ensure(n))) return rc;
+    if ((rc = s->ws.ensure(n, (int)W))) return rc;
     if ((rc = s->d_gen_start.ensure(n))) return rc;
     if ((rc = s->d_gen_len.ensure(n))) return rc;
     // adapters / scores outside the 2-bit path: every read goes the byte-wise way (frame_pack lists reads longer than 0 rows)

@@ -90,6 +90,25 @@ template <int W> __device__ __forceinline__ void load_row(const uint32_t *rows, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Task entries.  A work list of the filter and DP stages holds read indices; bit 31 of an entry says that the read's suffix
+// coordinate was still pending when k_scan wrote the span (so that the prefix pass can take a failed prefix's pending suffix
+// back, and push an accepted one on, without reading the span: dp_commit only stores).  A batch is at most 2^31 reads.
+// (Round 4 also built task RECORDS - the row copied by k_scan next to its index, dense per segment, every stage reading
+// records instead of gathering 40-byte rows: 470 MB less through the memory side per cfg-2 step of 2.86 GB, and no faster;
+// with 15 % substitutions, where nearly every read is a task and the "gather" is a stream already, 3 % slower.  What the step
+// follows is the number of L2 requests, not bytes: EXPERIMENTS R4.4.)
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kTaskSufPending = 1u << 31;
+constexpr uint32_t kTaskIndexMask = 0x7FFFFFFFu;
+struct TaskSrc { const uint32_t *rows; const uint16_t *lens; int W; };      // the batch the entries point into
+struct RecHead { uint32_t r; int n; bool suf_pending; };
+__device__ __forceinline__ RecHead task_head(const TaskSrc &src, uint32_t e) {
+    const uint32_t r = e & kTaskIndexMask;
+    return RecHead{r, (int)src.lens[r], (e & kTaskSufPending) != 0u};
+}
+__device__ __forceinline__ const uint32_t *task_row(const TaskSrc &src, uint32_t e) { return src.rows + (uint64_t)(e & kTaskIndexMask) * src.W; }
+
+// ------------------------------------------------------------------------------------------------
 // exact leftmost search of an m-base pattern in a packed read (memmem::find, lib.rs:148)
 //
 // Stage 1 compares only (up to) eight bases of each pattern at every start position: XOR-accumulate
@@ -133,13 +152,17 @@ template <int W> __device__ __forceinline__ void drop_candidate(uint32_t (&h)[W]
 #pragma unroll
     for (int w = 0; w < W; ++w) h[w] &= ~((pos >> 4) == (uint32_t)w ? bit : 0u);
 }
-// whole-pattern compare at start position p (p + m <= n <= 16 W)
-template <int W> __device__ __forceinline__ bool verify_at(const uint32_t *__restrict__ row, int p, uint64_t pat, int m) {
+// whole-pattern compare at start position p (p + m <= n <= 16 W).  row = the lane's column of the wave's row stage in LDS
+// (word w at row[w * WAVE]): three words at a dynamic offset, which registers cannot give.  Rounds 1-3 re-read them from
+// global memory - "L1-hot", except that a CU's 16 KB of L1 holds a fraction of the rows its twenty waves have in flight:
+// 3.5 M of k_scan's 7.8 M L2 requests a step and 1.3 M of its 4.6 M memory-side reads were these re-reads (a bare stream of
+// the same rows costs 3.1 M requests of 128 bytes and nothing more: scripts/ubench/row_stream.hip, profiles/r04_requests.json)
+template <int W> __device__ __forceinline__ bool verify_at(const uint32_t *row, int p, uint64_t pat, int m) {
     const int idx = p >> 4;
     const uint32_t bs = 2u * (uint32_t)(p & 15);
-    const uint32_t d0 = row[idx];
-    const uint32_t d1 = idx + 1 < W ? row[idx + 1] : 0u;
-    const uint32_t d2 = idx + 2 < W ? row[idx + 2] : 0u;
+    const uint32_t d0 = row[idx * WAVE];
+    const uint32_t d1 = idx + 1 < W ? row[(idx + 1) * WAVE] : 0u;
+    const uint32_t d2 = idx + 2 < W ? row[(idx + 2) * WAVE] : 0u;
     const uint32_t lo = funnel(d1, d0, bs), hi = funnel(d2, d1, bs);
     const uint64_t mask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
     const uint64_t diff = (((uint64_t)hi << 32 | lo) ^ pat) & mask;
@@ -147,7 +170,7 @@ template <int W> __device__ __forceinline__ bool verify_at(const uint32_t *__res
 }
 
 template <int W>
-__device__ __forceinline__ void exact_find2(const uint32_t (&r)[W + 2], const uint32_t *__restrict__ row, int n, const ScanParams &sp,
+__device__ __forceinline__ void exact_find2(const uint32_t (&r)[W + 2], const uint32_t *row, int n, const ScanParams &sp,
                                             int &ps, int &ss) {
     uint32_t accP[W], accS[W];
 #pragma unroll
@@ -220,6 +243,10 @@ __global__ VF_SCAN_ATTR void k_scan(const uint32_t *__restrict__ rows, const uin
                                                  uint64_t n_reads, ScanParams sp, short2 *__restrict__ spans,
                                                  BatchLists bl) {
     __shared__ uint32_t s_cnt[2];
+    // wave-private stage of the trip's rows, one column per lane ([word][lane]): the whole-pattern compare reads three words of
+    // it at a dynamic offset (verify_at)
+    __shared__ uint32_t s_stage[kBlock / WAVE][WAVE * W];
+    uint32_t *stg = s_stage[threadIdx.x / WAVE];
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
     if (blockIdx.x == 0 && threadIdx.x < 16) bl.tot[threadIdx.x] = 0;      // per-class task totals of the two filter passes
     __syncthreads();
@@ -246,13 +273,16 @@ __global__ VF_SCAN_ATTR void k_scan(const uint32_t *__restrict__ rows, const uin
         const int n = n_next;
         prefetch(r + stride);
         int ps, ss;
-        exact_find2<W>(x, rows + (valid ? r : 0) * W, n, sp, ps, ss);
+        __builtin_amdgcn_wave_barrier();              // (nobody is still comparing against the previous trip's rows: lanes only read their own column, but keep the order explicit)
+#pragma unroll
+        for (int w = 0; w < W; ++w) stg[w * WAVE + lane_id()] = x[w];
+        exact_find2<W>(x, stg + lane_id(), n, sp, ps, ss);
         int start = ps >= 0 ? ps + (int)sp.pre_len : (sp.align_pre ? (int)kPending : (int)kNone);
         int end = ss >= 0 ? ss : ((sp.align_suf && (sp.independent || start != kNone)) ? (int)kPending : (int)kNone);
         const bool needP = valid && start == kPending;
         const bool needS = valid && end == kPending && (sp.independent || start >= 0);
         const uint32_t ip = wave_append(&s_cnt[0], needP);
-        if (needP) bl.listP[seg0 + ip] = (uint32_t)r;
+        if (needP) bl.listP[seg0 + ip] = (uint32_t)r | (end == kPending ? kTaskSufPending : 0u);
         const uint32_t is = wave_append(&s_cnt[1], needS);
         if (needS) bl.listS[seg0 + is] = (uint32_t)r;
         if (valid) spans[r] = make_short2((short)start, (short)end);
@@ -390,20 +420,20 @@ __device__ __forceinline__ void dp_align(const uint32_t *__restrict__ row, int n
     dp_result<M>(HA, best_s, best_v, true, dp, score, len);
 }
 
-// outcome of one alignment task -> spans (+ suffix task for an accepted prefix)
-__device__ __forceinline__ bool dp_commit(bool valid, uint32_t r, int n, bool ok, int len, const DpParams &dp,
-                                          short2 *__restrict__ spans) {
+// outcome of one alignment task -> spans (+ suffix task for an accepted prefix).  Stores only, one 16-bit half each: the
+// prefix pass owns .x, the suffix pass .y (and the prefix pass takes a pending .y back when its alignment fails - whether
+// the suffix was pending is in the task's record, so nothing is read: rounds 1-3 read and re-wrote the whole span by index)
+__device__ __forceinline__ bool dp_commit(bool valid, const RecHead &h, bool ok, int len, const DpParams &dp, short2 *__restrict__ spans) {
     bool pushS = false;
     if (valid) {
-        short2 sp = spans[r];
+        short *sp = reinterpret_cast<short *>(spans + h.r);
         if (dp.is_prefix) {
-            sp.x = ok ? (short)len : kNone;
-            pushS = !dp.independent && ok && sp.y == kPending;
-            if (!dp.independent && !ok && sp.y == kPending) sp.y = kNone;
+            sp[0] = ok ? (short)len : kNone;
+            pushS = !dp.independent && ok && h.suf_pending;
+            if (!dp.independent && !ok && h.suf_pending) sp[1] = kNone;
         } else {
-            sp.y = (ok && len <= n) ? (short)(n - len) : kNone;
+            sp[1] = (ok && len <= h.n) ? (short)(h.n - len) : kNone;
         }
-        spans[r] = sp;
     }
     return pushS;
 }
@@ -452,7 +482,7 @@ __device__ __forceinline__ uint32_t flat_segment(const FlatList &f, uint32_t t) 
     return lo;
 }
 
-// append read r to the suffix list segment of its own scan workgroup (capacity: a read enters listS
+// append read `r` to the suffix list segment of its own scan workgroup (capacity: a read enters listS
 // at most once, by k_scan or by the prefix pass); lanes of a wave mostly share the segment
 __device__ __forceinline__ void push_suffix(const BatchLists &bl, uint32_t seg, uint32_t r, bool want) {
     uint64_t pending = __ballot(want);
@@ -471,7 +501,7 @@ __device__ __forceinline__ void push_suffix(const BatchLists &bl, uint32_t seg, 
 
 // Full-width DP over the tasks of the segmented list (list, cnt)
 template <int M>
-__device__ __forceinline__ void dp_full_body(FlatList &fl, DpLds &L, const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
+__device__ __forceinline__ void dp_full_body(FlatList &fl, DpLds &L, const TaskSrc &src,
                                              const DpParams &dp, short2 *__restrict__ spans, const BatchLists &bl,
                                              const uint32_t *__restrict__ list, const uint32_t *__restrict__ cnt,
                                              uint32_t count_stat, uint64_t *__restrict__ counters, uint32_t bid, uint32_t nb) {
@@ -481,30 +511,30 @@ __device__ __forceinline__ void dp_full_body(FlatList &fl, DpLds &L, const uint3
     const uint32_t n_round = (total + WAVE - 1) / WAVE * WAVE;
     for (uint32_t t = bid * kBlock + threadIdx.x; t < n_round; t += nb * kBlock) {
         const bool valid = t < total;
-        uint32_t r = 0, seg = 0;
-        int n = 0;
+        uint32_t ref = 0, seg = 0;
+        RecHead h{0u, 0, false};
         if (valid) {
             seg = flat_segment(fl, t);
-            r = list[(uint64_t)seg * bl.seg + (t - fl.pre[seg])];
-            n = lens[r];
+            ref = list[(uint64_t)seg * bl.seg + (t - fl.pre[seg])];
+            h = task_head(src, ref);
         }
         int score, len;
-        dp_align<M>(rows + (uint64_t)r * W, n, dp, L, score, len);
-        const bool pushS = dp_commit(valid, r, n, score >= dp.T, len, dp, spans);
-        if (dp.is_prefix) push_suffix(bl, seg, r, pushS);
+        dp_align<M>(task_row(src, ref), h.n, dp, L, score, len);
+        const bool pushS = dp_commit(valid, h, score >= dp.T, len, dp, spans);
+        if (dp.is_prefix) push_suffix(bl, seg, ref, pushS);
     }
     if (bid == 0 && threadIdx.x == 0 && count_stat && total)
         atomicAdd((unsigned long long *)&counters[dp.is_prefix ? C_DP_PREFIX : C_DP_SUFFIX], (unsigned long long)total);
 }
 
 template <int M>
-__global__ __launch_bounds__(kBlock) void k_dp(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
+__global__ __launch_bounds__(kBlock) void k_dp(int W,
                                                DpParams dp, short2 *__restrict__ spans, BatchLists bl,
                                                const uint32_t *__restrict__ list, const uint32_t *__restrict__ cnt,
                                                uint32_t count_stat, uint64_t *__restrict__ counters) {
     __shared__ FlatList fl;
     __shared__ DpLds L;
-    dp_full_body<M>(fl, L, rows, lens, W, dp, spans, bl, list, cnt, count_stat, counters, blockIdx.x, gridDim.x);
+    dp_full_body<M>(fl, L, TaskSrc{bl.rows, bl.lens, W}, dp, spans, bl, list, cnt, count_stat, counters, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -650,6 +680,9 @@ constexpr int kBandN = 5;        // ... and for the narrow class of the block fi
 #endif
 constexpr int kBandW = VF_BAND_W;
 constexpr int kBandBias = 4096;  // class-0 window word = first diagonal + kBandBias
+#ifndef VF_HAMMING_CERT
+#define VF_HAMMING_CERT 1       // (A/B: make variant NAME=noham DEFS=-DVF_HAMMING_CERT=0)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // k_bfilter: the block filter, in front of the Myers pass.
@@ -784,12 +817,90 @@ __device__ __forceinline__ bool wide_band_class(const Clusters &cl, const DpPara
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The Hamming certificate (round 4): classes 0 / 6 for single-cluster tasks with TWO OR MORE substitutions.
+// Lay the adapter on the cluster's centre diagonal(s) - end column jc = (jmin + jmax) / 2, read bases [jc - m, jc) - and count
+// the bases that differ: h.  That ungapped alignment scores match*m - h*(match - mismatch), so the task's optimum is
+// S* >= T'' = max(T, that), and every OPTIMAL alignment has at most kq = max_unit_errors(T'') unit edits (host: fill_dp,
+// dp.kerr_h[h]; kq >= h, so the certified column itself has D <= h <= kq).  The rest is the class-0 argument with kq in the
+// place of kerr_lo: end columns of optimal alignments have D <= kq, D moves by at most one per column, so
+// they lie kerr - kq columns inside the cluster [jmin, jmax] of columns with D <= kerr on every side the read does not cut
+// off: [lo, hi]; alignments with at most kq gap or overhang bases ending there stay on the diagonals
+// [lo - m - kq, hi - m + kq].  A copy with two substitutions (defaults, m = 20: T'' = 50, kq = 3, cluster 7 columns wide)
+// gets 2 + 6 + 1 = 9 diagonals - class 0 - where the plain bound kerr = 5 gave 6 + 10 + 1 = 17 > kBandW and the task took a
+// 64-column window (546 k of the 1.72 M prefix tasks per 2 M reads of the cfg-4 shape, 70 % of that pass's DP cells).
+// tests/tools/band_model.py::hamming_case restates decision and band on the CPU against the full-matrix DP.
+// ------------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void hamming_band_class(const uint32_t *__restrict__ row, int n, const Clusters &cl, const DpParams &dp, bool cand,
+                                                   int &cls, int &av) {
+    if (!__any(cand)) return;
+    const int m = (int)dp.m;
+    const uint64_t patmask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
+    int hmin = 64;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int jc = (cl.jmin1 + cl.jmax1 + e) >> 1;
+        const int d = jc - m;
+        const bool fits = cand && d >= 0 && jc <= n;           // the whole adapter lies inside the read on this diagonal
+        const int idx = fits ? d >> 4 : 0;
+        const uint32_t bsh = 2u * (uint32_t)((fits ? d : 0) & 15);
+        uint32_t d0 = 0, d1 = 0, d2 = 0;
+        if (fits) {
+            d0 = row[idx];
+            d1 = idx + 1 < W ? row[idx + 1] : 0u;
+            d2 = idx + 2 < W ? row[idx + 2] : 0u;
+        }
+        const uint32_t lo = funnel(d1, d0, bsh), hi = funnel(d2, d1, bsh);
+        uint64_t diff = ((((uint64_t)hi << 32) | lo) ^ dp.pat) & patmask;
+        diff = (diff | (diff >> 1)) & 0x5555555555555555ull;
+        const int h = fits ? (int)__popcll(diff) : 64;
+        hmin = min(hmin, h);
+    }
+    int kq = -1;
+#pragma unroll
+    for (int h = 1; h < 8; ++h) kq = hmin == h ? dp.kerr_h[h] : kq;
+    if (!cand || kq < 1 || kq >= dp.kerr) return;
+    const int dl = dp.kerr - kq;
+    const int lo = cl.jmin1 > 1 ? cl.jmin1 + dl : 1;
+    const int hi = cl.jmax1 < n ? cl.jmax1 - dl : n;
+    if (hi < lo) return;
+    const int width = hi - lo + 2 * kq + 1;
+    if (width <= kBand) { cls = 0; av = lo - m - kq; }
+    else if (width <= kBandW) { cls = 6; av = lo - m - kq; }
+}
+
+// What the Myers pass makes of one task's clusters: cls 0 banded (kBand), 1..3 windowed, 4 whole read, 6 wide band (kBandW);
+// av = first diagonal of a banded class, a1 / a2 = window starts.  (One place for k_filter and k_bmfilter's Myers stage.)
+template <int W>
+__device__ __forceinline__ void myers_classify(const uint32_t *__restrict__ row, int n, bool any, const Clusters &cl, const DpParams &dp,
+                                               int &cls, int &av, int &a1, int &a2) {
+    const int base = (int)dp.m + dp.kerr;
+    a1 = max(0, cl.jmin1 - base); a2 = max(0, cl.jmin2 - base);
+    cls = window_class(cl, a1, a2, base, dp.kerr);
+    av = 0;
+    // A task whose best own column has unit edit distance <= 1 has an optimum of at least match*m - c_max,
+    // so all its optimal alignments have at most kerr_lo unit edits (host: fill_dp).  Their end columns
+    // have D <= kerr_lo; D changes by at most one per column, so such a column lies kerr - kerr_lo columns
+    // inside the cluster of columns with D <= kerr on every side the read does not cut off.  The cells on
+    // those alignments lie on the diagonals j - i in [lo - m - kerr_lo, hi - m + kerr_lo]: class 0 when
+    // that band is at most kBand wide.
+    if (dp.kerr_lo >= 0 && cl.dmin <= 1 && cl.ncl == 1) {
+        const int dl = dp.kerr - dp.kerr_lo;
+        const int lo = cl.jmin1 > 1 ? cl.jmin1 + dl : 1;
+        const int hi = cl.jmax1 < n ? cl.jmax1 - dl : n;
+        if (hi >= lo && hi - lo + 2 * dp.kerr_lo + 1 <= kBand) { cls = 0; av = lo - (int)dp.m - dp.kerr_lo; }
+    }
+    if (VF_HAMMING_CERT) hamming_band_class<W>(row, n, cl, dp, any && cls != 0 && cl.ncl == 1 && dp.kerr_h[0] != 0, cls, av);
+    if (cls != 0 && cls != 6 && wide_band_class(cl, dp, av)) cls = 6;
+}
+
 // the Myers pass alone, over every task of the adapter's list (scoring schemes that give the block filter no bound, or
 // VFIND_BLOCK_FILTER=0)
 template <int W>
-__global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens,
-                                                   DpParams dp, short2 *__restrict__ spans, BatchLists bl,
+__global__ __launch_bounds__(kBlock) void k_filter(DpParams dp, short2 *__restrict__ spans, BatchLists bl,
                                                    uint64_t *__restrict__ counters) {
+    const TaskSrc src{bl.rows, bl.lens, W};
     __shared__ uint32_t s_c[6];
     __shared__ uint2 s_eq2[16];
     if (threadIdx.x < 16) s_eq2[threadIdx.x] = make_uint2(dp.eq_top[threadIdx.x & 3], dp.eq_top[threadIdx.x >> 2]);
@@ -804,32 +915,17 @@ __global__ __launch_bounds__(kBlock) void k_filter(const uint32_t *__restrict__ 
         const uint64_t seg0 = (uint64_t)b * bl.seg;
         for (uint32_t t = threadIdx.x; t < n_round; t += kBlock) {
             const bool valid = t < ntask;
-            uint32_t r = 0;
+            uint32_t r = 0;                              // (a task entry from here on)
             int n = 0;
-            if (valid) { r = list[seg0 + t]; n = lens[r]; }
+            if (valid) { r = list[seg0 + t]; n = (int)src.lens[r & kTaskIndexMask]; }
             Clusters cl;
             uint32_t x0[10];
-            myers_first_chunk(rows + (uint64_t)r * W, n, x0);
-            myers_scan<W>(rows + (uint64_t)r * W, n, dp, s_eq2, cl, x0);
+            myers_first_chunk(task_row(src, r), n, x0);
+            myers_scan<W>(task_row(src, r), n, dp, s_eq2, cl, x0);
             const bool any = valid && cl.ncl > 0;
-            if (valid && !any) (void)dp_commit(true, r, n, false, 0, dp, spans);
-            const int base = (int)dp.m + dp.kerr;
-            const int a1 = max(0, cl.jmin1 - base), a2 = max(0, cl.jmin2 - base);
-            int cls = window_class(cl, a1, a2, base, dp.kerr);
-            // A task whose best own column has unit edit distance <= 1 has an optimum of at least match*m - c_max,
-            // so all its optimal alignments have at most kerr_lo unit edits (host: fill_dp).  Their end columns
-            // have D <= kerr_lo; D changes by at most one per column, so such a column lies kerr - kerr_lo columns
-            // inside the cluster of columns with D <= kerr on every side the read does not cut off.  The cells on
-            // those alignments lie on the diagonals j - i in [lo - m - kerr_lo, hi - m + kerr_lo]: class 0 when
-            // that band is at most kBand wide.
-            int av = 0;
-            if (dp.kerr_lo >= 0 && cl.dmin <= 1 && cl.ncl == 1) {
-                const int dl = dp.kerr - dp.kerr_lo;
-                const int lo = cl.jmin1 > 1 ? cl.jmin1 + dl : 1;
-                const int hi = cl.jmax1 < n ? cl.jmax1 - dl : n;
-                if (hi >= lo && hi - lo + 2 * dp.kerr_lo + 1 <= kBand) { cls = 0; av = lo - (int)dp.m - dp.kerr_lo; }
-            }
-            if (cls != 0 && wide_band_class(cl, dp, av)) cls = 6;
+            if (valid && !any) (void)dp_commit(true, task_head(src, r), false, 0, dp, spans);      // (the header again: nothing of it is kept across the scan)
+            int cls, av, a1, a2;
+            myers_classify<W>(task_row(src, r), n, any, cl, dp, cls, av, a1, a2);
             {
                 const bool toB = any && cls == 6;
                 const uint32_t ib = wave_append(&s_c[5], toB);
@@ -885,7 +981,7 @@ struct TripIter {
 };
 
 template <int W, int NB>
-__device__ __forceinline__ void front_bf_stage(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, const DpParams &dp,
+__device__ __forceinline__ void front_bf_stage(const TaskSrc &src, const DpParams &dp,
                                                const uint32_t *list, uint32_t ntask, const ClassSet &cs, uint64_t seg0, uint32_t *s_c,
                                                uint32_t *rowcol) {
     // the task index is fetched a trip ahead, the row is not: a second row in registers (12 more, 106 in all) cost the
@@ -900,7 +996,7 @@ __device__ __forceinline__ void front_bf_stage(const uint32_t *__restrict__ rows
         const bool valid = v_n;
         uint32_t x[W + 2];
         int n = 0;
-        if (valid) { n = lens[r]; load_row<W>(rows, r, x); }
+        if (valid) { n = (int)src.lens[r & kTaskIndexMask]; load_row<W>(src.rows, r & kTaskIndexMask, x); }      // (r: a task entry)
         else {
 #pragma unroll
             for (int k = 0; k < W + 2; ++k) x[k] = 0;
@@ -924,7 +1020,7 @@ __device__ __forceinline__ void front_bf_stage(const uint32_t *__restrict__ rows
 // s_my[0] starts at the number of class-0 tasks the block filter put into the segment) or "no alignment can pass".
 // Task index one trip ahead.
 template <int W>
-__device__ __forceinline__ void front_myers_stage(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, const DpParams &dp,
+__device__ __forceinline__ void front_myers_stage(const TaskSrc &src, const DpParams &dp,
                                                   short2 *__restrict__ spans, const ClassSet &cs, uint32_t nR, uint64_t seg0,
                                                   uint32_t *s_my, const uint2 *s_eq2) {
     TripIter it(nR);
@@ -933,28 +1029,19 @@ __device__ __forceinline__ void front_myers_stage(const uint32_t *__restrict__ r
     bool v_n = t < nR;
     uint32_t r_n = v_n ? cs.listR[seg0 + t] : 0u;
     for (uint32_t i = 0; i < ntrip; ++i, t += kBlock) {
-        const uint32_t r = r_n;
+        const uint32_t r = r_n;                          // (a task entry)
         const bool valid = v_n;
-        const int n = valid ? (int)lens[r] : 0;
+        const int n = valid ? (int)src.lens[r & kTaskIndexMask] : 0;
         uint32_t x0[10];
-        myers_first_chunk(rows + (uint64_t)r * W, n, x0);
+        myers_first_chunk(task_row(src, r), n, x0);
         v_n = t + kBlock < nR;
         r_n = v_n ? cs.listR[seg0 + t + kBlock] : 0u;
         Clusters cl;
-        myers_scan<W>(rows + (uint64_t)r * W, n, dp, s_eq2, cl, x0);
+        myers_scan<W>(task_row(src, r), n, dp, s_eq2, cl, x0);
         const bool any = valid && cl.ncl > 0;
-        if (valid && !any) (void)dp_commit(true, r, n, false, 0, dp, spans);
-        const int base = (int)dp.m + dp.kerr;
-        const int a1 = max(0, cl.jmin1 - base), a2 = max(0, cl.jmin2 - base);
-        int cls = window_class(cl, a1, a2, base, dp.kerr);
-        int av = 0;
-        if (dp.kerr_lo >= 0 && cl.dmin <= 1 && cl.ncl == 1) {          // class 0 of the Myers filter (k_filter)
-            const int dl = dp.kerr - dp.kerr_lo;
-            const int lo = cl.jmin1 > 1 ? cl.jmin1 + dl : 1;
-            const int hi = cl.jmax1 < n ? cl.jmax1 - dl : n;
-            if (hi >= lo && hi - lo + 2 * dp.kerr_lo + 1 <= kBand) { cls = 0; av = lo - (int)dp.m - dp.kerr_lo; }
-        }
-        if (cls != 0 && wide_band_class(cl, dp, av)) cls = 6;
+        if (valid && !any) (void)dp_commit(true, task_head(src, r), false, 0, dp, spans);      // (the header again: nothing of it is kept across the scan)
+        int cls, av, a1, a2;
+        myers_classify<W>(task_row(src, r), n, any, cl, dp, cls, av, a1, a2);
         {
             const bool toB = any && cls == 6;
             const uint32_t ib = wave_append(&s_my[5], toB);
@@ -980,8 +1067,9 @@ __device__ __forceinline__ void front_myers_stage(const uint32_t *__restrict__ r
 // task segment through the block filter, then its rest through the Myers filter -- one launch and one tail per adapter
 // instead of two, the rest list never leaves the workgroup.
 template <int W, int NB>
-__global__ __launch_bounds__(kBlock) void k_bmfilter(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, DpParams dp,
+__global__ __launch_bounds__(kBlock) void k_bmfilter(DpParams dp,
                                                      short2 *__restrict__ spans, BatchLists bl, uint64_t *__restrict__ counters) {
+    const TaskSrc src{bl.rows, bl.lens, W};
     __shared__ uint32_t s_bf[3];
     __shared__ uint32_t s_my[6];
     __shared__ uint2 s_eq2[16];
@@ -1001,12 +1089,12 @@ __global__ __launch_bounds__(kBlock) void k_bmfilter(const uint32_t *__restrict_
         if (threadIdx.x < 6) s_my[threadIdx.x] = 0;
         __syncthreads();
         const uint64_t seg0 = (uint64_t)sb * bl.seg;
-        if (ntask) front_bf_stage<W, NB>(rows, lens, dp, list, ntask, cs, seg0, s_bf, s_row + threadIdx.x);
+        if (ntask) front_bf_stage<W, NB>(src, dp, list, ntask, cs, seg0, s_bf, s_row + threadIdx.x);
         __syncthreads();
         const uint32_t nR = s_bf[2];
         if (threadIdx.x == 0) s_my[0] = s_bf[1];
         __syncthreads();
-        if (nR) front_myers_stage<W>(rows, lens, dp, spans, cs, nR, seg0, s_my, s_eq2);
+        if (nR) front_myers_stage<W>(src, dp, spans, cs, nR, seg0, s_my, s_eq2);
         __syncthreads();
         if (threadIdx.x == 0) {
             bl.cntN[sb] = s_bf[0]; bl.cntR[sb] = nR;
@@ -1078,7 +1166,7 @@ __device__ __forceinline__ void dp_window(const uint32_t *__restrict__ row, int 
 }
 
 template <int M, bool TWO>
-__device__ __forceinline__ void dpw_body(FlatList &fl, DpLds &L, const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
+__device__ __forceinline__ void dpw_body(FlatList &fl, DpLds &L, const TaskSrc &src, int W,
                                          const DpParams &dp, short2 *__restrict__ spans, const BatchLists &bl, int cls, uint32_t bid, uint32_t nb) {
     dp_lds_fill(L, dp);
     const uint32_t *list = bl.listW[cls], *win = bl.winW[cls];
@@ -1087,13 +1175,14 @@ __device__ __forceinline__ void dpw_body(FlatList &fl, DpLds &L, const uint32_t 
     const uint32_t n_round = (total + WAVE - 1) / WAVE * WAVE;
     for (uint32_t t = bid * kBlock + threadIdx.x; t < n_round; t += nb * kBlock) {
         const bool valid = t < total;
-        uint32_t r = 0, seg = 0;
-        int n = 0, wa = 0, wb = 0, wa2 = 0, wb2 = 0;
+        uint32_t r = 0, seg = 0;                         // (r: a record index)
+        RecHead h{0u, 0, false};
+        int wa = 0, wb = 0, wa2 = 0, wb2 = 0;
         if (valid) {
             seg = flat_segment(fl, t);
             const uint64_t at = (uint64_t)seg * bl.seg + (t - fl.pre[seg]);
             r = list[at];
-            n = lens[r];
+            h = task_head(src, r);
             const uint32_t w = win[at];
             wa = (int)(w & 0xFFFFu);
             wb = (int)(w >> 16);
@@ -1104,8 +1193,8 @@ __device__ __forceinline__ void dpw_body(FlatList &fl, DpLds &L, const uint32_t 
             }
         }
         int score, len;
-        dp_window<M, TWO>(rows + (uint64_t)r * W, W, n, wa, wb, wa2, wb2, dp, L, score, len);
-        const bool pushS = dp_commit(valid, r, n, score >= dp.T, len, dp, spans);
+        dp_window<M, TWO>(task_row(src, r), W, h.n, wa, wb, wa2, wb2, dp, L, score, len);
+        const bool pushS = dp_commit(valid, h, score >= dp.T, len, dp, spans);
         if (dp.is_prefix) push_suffix(bl, seg, r, pushS);
     }
 }
@@ -1193,7 +1282,7 @@ __device__ __forceinline__ void dp_banded(const uint32_t *__restrict__ row, int 
 }
 
 template <int M, int B>
-__device__ __forceinline__ void dpb_body(FlatList &fl, DpLds &L, const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
+__device__ __forceinline__ void dpb_body(FlatList &fl, DpLds &L, const TaskSrc &src, int W,
                                          const DpParams &dp, short2 *__restrict__ spans, const BatchLists &bl,
                                          const uint32_t *__restrict__ list, const uint32_t *__restrict__ win, const uint32_t *__restrict__ cnt,
                                          uint32_t bid, uint32_t nb) {
@@ -1203,18 +1292,19 @@ __device__ __forceinline__ void dpb_body(FlatList &fl, DpLds &L, const uint32_t 
     const uint32_t n_round = (total + WAVE - 1) / WAVE * WAVE;
     for (uint32_t t = bid * kBlock + threadIdx.x; t < n_round; t += nb * kBlock) {
         const bool valid = t < total;
-        uint32_t r = 0, seg = 0;
-        int n = 0, av = 0;
+        uint32_t r = 0, seg = 0;                         // (r: a record index)
+        RecHead h{0u, 0, false};
+        int av = 0;
         if (valid) {
             seg = flat_segment(fl, t);
             const uint64_t at = (uint64_t)seg * bl.seg + (t - fl.pre[seg]);
             r = list[at];
-            n = lens[r];
+            h = task_head(src, r);
             av = (int)win[at] - kBandBias;
         }
         int score, len;
-        dp_banded<M, B>(rows + (uint64_t)r * W, W, n, av, dp, L, score, len);
-        const bool pushS = dp_commit(valid, r, n, score >= dp.T, len, dp, spans);
+        dp_banded<M, B>(task_row(src, r), W, h.n, av, dp, L, score, len);
+        const bool pushS = dp_commit(valid, h, score >= dp.T, len, dp, spans);
         if (dp.is_prefix) push_suffix(bl, seg, r, pushS);
     }
 }
@@ -1285,7 +1375,7 @@ __device__ __forceinline__ void dp_coop(const uint32_t *__restrict__ row, int W,
 
 // classes 3 (two windows: their hull) and 4 (whole read), one task per wave
 template <int M>
-__device__ __forceinline__ void dpc_body(FlatList &fl, const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
+__device__ __forceinline__ void dpc_body(FlatList &fl, const TaskSrc &src, int W,
                                          const DpParams &dp, short2 *__restrict__ spans, const BatchLists &bl, bool two_windows,
                                          uint32_t *s_rows, uint32_t bid, uint32_t nb) {
     const uint32_t *list = two_windows ? bl.listW[3] : bl.listF;
@@ -1296,14 +1386,15 @@ __device__ __forceinline__ void dpc_body(FlatList &fl, const uint32_t *__restric
     for (uint32_t t = bid * nwaves + wave; t < total; t += nb * nwaves) {          // wave-uniform
         const uint32_t seg = flat_segment(fl, t);
         const uint64_t at = (uint64_t)seg * bl.seg + (t - fl.pre[seg]);
-        const uint32_t r = list[at];
-        const int n = lens[r];
+        const uint32_t r = list[at];                     // (a task entry)
+        const RecHead h = task_head(src, r);
+        const int n = h.n;
         int a = 0, b = n;
         if (two_windows) { a = (int)(bl.winW[3][at] & 0xFFFFu); b = (int)(bl.winW2[at] >> 16); }
         int score = INT32_MIN / 2, len = 0;
-        if (b - a > 0) dp_coop<M>(rows + (uint64_t)r * W, W, n, a, b, dp, s_row, score, len);
+        if (b - a > 0) dp_coop<M>(task_row(src, r), W, n, a, b, dp, s_row, score, len);
         const bool lead = lane_id() == 0;
-        const bool pushS = dp_commit(lead, r, n, score >= dp.T, len, dp, spans);
+        const bool pushS = dp_commit(lead, h, score >= dp.T, len, dp, spans);
         if (dp.is_prefix) push_suffix(bl, seg, r, pushS);
         __builtin_amdgcn_wave_barrier();
     }
@@ -1328,8 +1419,9 @@ __device__ uint64_t g_dp_trace[2][kMaxGrid][4];
 #define VF_DP_CLASS(c) do {} while (0)
 #endif
 template <int M>
-__global__ __launch_bounds__(kBlock) void k_dpall(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens, int W,
+__global__ __launch_bounds__(kBlock) void k_dpall(int W,
                                                   DpParams dp, short2 *__restrict__ spans, BatchLists bl, uint64_t *__restrict__ counters) {
+    const TaskSrc src{bl.rows, bl.lens, W};
     __shared__ FlatList fl;
     __shared__ DpLds L;
     __shared__ uint32_t s_rows[(kBlock / WAVE) * 40];
@@ -1382,28 +1474,28 @@ __global__ __launch_bounds__(kBlock) void k_dpall(const uint32_t *__restrict__ r
     uint32_t b0 = 0;
     const uint32_t b = blockIdx.x;
     VF_DP_STAMP(2);
-    if (b < b0 + nbk[5]) { VF_DP_CLASS(5); dpb_body<M, kBandN>(fl, L, rows, lens, W, dp, spans, bl, bl.listN, bl.winN, bl.cntN, b - b0, nbk[5]); VF_DP_STAMP(3); return; }
+    if (b < b0 + nbk[5]) { VF_DP_CLASS(5); dpb_body<M, kBandN>(fl, L, src, W, dp, spans, bl, bl.listN, bl.winN, bl.cntN, b - b0, nbk[5]); VF_DP_STAMP(3); return; }
     b0 += nbk[5];
-    if (b < b0 + nbk[0]) { VF_DP_CLASS(0); dpb_body<M, kBand>(fl, L, rows, lens, W, dp, spans, bl, bl.listW[0], bl.winW[0], bl.cntW[0], b - b0, nbk[0]); VF_DP_STAMP(3); return; }
+    if (b < b0 + nbk[0]) { VF_DP_CLASS(0); dpb_body<M, kBand>(fl, L, src, W, dp, spans, bl, bl.listW[0], bl.winW[0], bl.cntW[0], b - b0, nbk[0]); VF_DP_STAMP(3); return; }
     b0 += nbk[0];
-    if (b < b0 + nbk[6]) { VF_DP_CLASS(6); dpb_body<M, kBandW>(fl, L, rows, lens, W, dp, spans, bl, bl.listB, bl.winB, bl.cntB, b - b0, nbk[6]); VF_DP_STAMP(3); return; }
+    if (b < b0 + nbk[6]) { VF_DP_CLASS(6); dpb_body<M, kBandW>(fl, L, src, W, dp, spans, bl, bl.listB, bl.winB, bl.cntB, b - b0, nbk[6]); VF_DP_STAMP(3); return; }
     b0 += nbk[6];
-    if (b < b0 + nbk[1]) { VF_DP_CLASS(1); dpw_body<M, false>(fl, L, rows, lens, W, dp, spans, bl, 1, b - b0, nbk[1]); VF_DP_STAMP(3); return; }
+    if (b < b0 + nbk[1]) { VF_DP_CLASS(1); dpw_body<M, false>(fl, L, src, W, dp, spans, bl, 1, b - b0, nbk[1]); VF_DP_STAMP(3); return; }
     b0 += nbk[1];
-    if (b < b0 + nbk[2]) { VF_DP_CLASS(2); dpw_body<M, false>(fl, L, rows, lens, W, dp, spans, bl, 2, b - b0, nbk[2]); VF_DP_STAMP(3); return; }
+    if (b < b0 + nbk[2]) { VF_DP_CLASS(2); dpw_body<M, false>(fl, L, src, W, dp, spans, bl, 2, b - b0, nbk[2]); VF_DP_STAMP(3); return; }
     b0 += nbk[2];
     if (b < b0 + nbk[3]) {
         VF_DP_CLASS(3);
-        if (coop3) dpc_body<M>(fl, rows, lens, W, dp, spans, bl, true, s_rows, b - b0, nbk[3]);
-        else dpw_body<M, true>(fl, L, rows, lens, W, dp, spans, bl, 3, b - b0, nbk[3]);
+        if (coop3) dpc_body<M>(fl, src, W, dp, spans, bl, true, s_rows, b - b0, nbk[3]);
+        else dpw_body<M, true>(fl, L, src, W, dp, spans, bl, 3, b - b0, nbk[3]);
         VF_DP_STAMP(3);
         return;
     }
     b0 += nbk[3];
     if (b < b0 + nbk[4]) {
         VF_DP_CLASS(4);
-        if (coop4) dpc_body<M>(fl, rows, lens, W, dp, spans, bl, false, s_rows, b - b0, nbk[4]);
-        else dp_full_body<M>(fl, L, rows, lens, W, dp, spans, bl, bl.listF, bl.cntF, 0u, counters, b - b0, nbk[4]);
+        if (coop4) dpc_body<M>(fl, src, W, dp, spans, bl, false, s_rows, b - b0, nbk[4]);
+        else dp_full_body<M>(fl, L, src, dp, spans, bl, bl.listF, bl.cntF, 0u, counters, b - b0, nbk[4]);
         VF_DP_STAMP(3);
     }
 }
@@ -1614,6 +1706,10 @@ __device__ __forceinline__ int arena_alloc(BlockTable &bt, const Table &t, uint3
     return kAllocOk;
 }
 
+__device__ __forceinline__ void slot_load_key(const uint4 *p, uint32_t nd, bool can, uint32_t tag, uint4 &a, uint4 &b, uint4 &c, uint4 &d);
+#ifndef VF_SLOW_PARTIAL
+#define VF_SLOW_PARTIAL 1       // (A/B: make variant NAME=slowfull DEFS=-DVF_SLOW_PARTIAL=0: whole slot lines in the insert queue, as until round 4)
+#endif
 // Finds key's slot, inserting the key if absent; returns kNoSlot on a capacity error.
 // have_off: arena offset the (LONG) key already occupies (table growth re-inserts entries whose keys stay where they
 // are), kNoOff = the key is copied into a fresh arena allocation.
@@ -1673,7 +1769,12 @@ __device__ __forceinline__ uint32_t table_find_or_insert(const Table &t, BlockTa
             // reader took the letters an earlier epoch had left in key[0..1] for an arena offset).
             bool image_older = false;
             if (!claimed) {
-                slot_load(sp, l0, l1, l2, l3);
+                // Only the 16-byte quarters of the line this lane's key reaches (a LONG key: w0 and the offset word), as in the
+                // one-shot lookup: a quarter is one request at the L2, and the queue's loop was 4 of them a trip for every lane
+                // in it (round 4's request table: ~5 M of k_finish's 18.8 M read requests a step).  A slot whose w0 matches holds
+                // a key of the same length, padded like this one, so the quarters left out compare equal by construction.
+                if (VF_SLOW_PARTIAL) slot_load_key(sp, is_long ? 2u : nd, true, selfval ? t.key_tag : 0u, l0, l1, l2, l3);
+                else slot_load(sp, l0, l1, l2, l3);
                 w0 = (uint64_t)l0.x | ((uint64_t)l0.y << 32);
                 if (w0_free(t, w0)) {
                     const uint64_t seen = w0;                    // (0, or a word of an earlier epoch: the CAS expects exactly it)
@@ -2463,46 +2564,70 @@ __device__ __forceinline__ void part_starts(const uint32_t *__restrict__ tot, ui
 }
 
 // One workgroup per workgroup of k_finish: its four wave segments and its pairs, grouped by slot part.  A run per part is
-// reserved in the part's stretch of the output with one atomic (the totals say where the stretch starts), the entries
-// take their places inside the run through LDS counters; the 4-byte stores of a run fill its lines in L2.
+// reserved in the part's stretch of the output with one atomic (the totals say where the stretch starts).  The single
+// occurrences - the bulk: ~3 M a cfg-2 step - are first put in part order in LDS and leave as whole runs, consecutive lanes to
+// consecutive addresses: placed one by one (rounds 3) every entry was a 4-byte write request of its own at the L2, 2.7 M of
+// them a step (profiles/r04_requests.json), and the step follows the number of L2 requests (EXPERIMENTS R4.4).
+constexpr uint32_t kScatterChunk = 4096;                  // entries sorted in LDS at a time
 __global__ __launch_bounds__(kBlock) void k_log_scatter(CountLog log, uint64_t *__restrict__ counters) {
     __shared__ uint32_t s_start[2][kLogMaxParts + 1];     // part starts (one, many)
     __shared__ uint32_t s_n[2][kLogMaxParts];             // this workgroup's entries per part, then its cursor
     __shared__ uint32_t s_base[2][kLogMaxParts];
+    __shared__ uint32_t s_loc[kLogMaxParts + 1];          // the chunk's part starts inside s_sorted
+    __shared__ uint32_t s_sorted[kScatterChunk];
     const uint32_t P = log.parts;
     part_starts(log.tot, P, s_start[0]);
     part_starts(log.tot + kLogMaxParts, P, s_start[1]);
-    for (uint32_t i = threadIdx.x; i < 2 * kLogMaxParts; i += kBlock) (&s_n[0][0])[i] = 0;
-    __syncthreads();
     const uint32_t b = blockIdx.x;
-    const uint32_t n_many = log.n_many[b];
-    const uint2 *many = log.many + (uint64_t)b * kLogMany;
-    // count
-    for (uint32_t w = 0; w < kBlock / WAVE; ++w) {
-        const uint32_t gw = b * (kBlock / WAVE) + w, n = log.n_one[gw];
-        const uint32_t *seg = log.one + (uint64_t)gw * log.cap_one;
-        for (uint32_t i = threadIdx.x; i < n; i += kBlock) atomicAdd(&s_n[0][seg[i] >> log.shift], 1u);
-    }
-    for (uint32_t i = threadIdx.x; i < n_many; i += kBlock) atomicAdd(&s_n[1][many[i].x >> log.shift], 1u);
-    __syncthreads();
-    // reserve
-    for (uint32_t i = threadIdx.x; i < 2 * P; i += kBlock) {
-        const uint32_t k = i / P, p = i % P, n = s_n[k][p];
-        s_base[k][p] = s_start[k][p] + (n ? atomicAdd(&log.cur[k * kLogMaxParts + p], n) : 0u);
-        s_n[k][p] = 0;
-    }
-    __syncthreads();
-    // place
     bool bad = false;
-    for (uint32_t w = 0; w < kBlock / WAVE; ++w) {
-        const uint32_t gw = b * (kBlock / WAVE) + w, n = log.n_one[gw];
-        const uint32_t *seg = log.one + (uint64_t)gw * log.cap_one;
-        for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
-            const uint32_t slot = seg[i], p = slot >> log.shift;
-            const uint64_t at = (uint64_t)s_base[0][p] + atomicAdd(&s_n[0][p], 1u);
+    // ---- single occurrences: the four wave segments as one sequence, a chunk at a time
+    uint32_t seg_n[kBlock / WAVE], total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlock / WAVE; ++w) { seg_n[w] = log.n_one[b * (kBlock / WAVE) + w]; total += seg_n[w]; }
+    auto entry = [&](uint32_t i) -> uint32_t {            // i-th entry of the workgroup (i < total)
+        uint32_t w = 0;
+#pragma unroll
+        for (uint32_t k = 0; k + 1 < kBlock / WAVE; ++k) if (w == k && i >= seg_n[k]) { i -= seg_n[k]; w = k + 1; }
+        return log.one[(uint64_t)(b * (kBlock / WAVE) + w) * log.cap_one + i];
+    };
+    for (uint32_t c0 = 0; c0 < total; c0 += kScatterChunk) {              // (workgroup-uniform)
+        const uint32_t cn = min(kScatterChunk, total - c0);
+        for (uint32_t i = threadIdx.x; i < kLogMaxParts; i += kBlock) s_n[0][i] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cn; i += kBlock) atomicAdd(&s_n[0][entry(c0 + i) >> log.shift], 1u);
+        __syncthreads();
+        part_starts(s_n[0], P, s_loc);                                     // (ends with a barrier)
+        for (uint32_t p = threadIdx.x; p < P; p += kBlock) {
+            const uint32_t n = s_n[0][p];
+            s_base[0][p] = s_start[0][p] + (n ? atomicAdd(&log.cur[p], n) : 0u);
+            s_n[0][p] = 0;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cn; i += kBlock) {
+            const uint32_t slot = entry(c0 + i), p = slot >> log.shift;
+            s_sorted[s_loc[p] + atomicAdd(&s_n[0][p], 1u)] = slot;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cn; i += kBlock) {
+            const uint32_t slot = s_sorted[i], p = slot >> log.shift;
+            const uint64_t at = (uint64_t)s_base[0][p] + (i - s_loc[p]);
             if (at < log.cap_total) log.one_by_part[at] = slot; else bad = true;
         }
+        __syncthreads();
     }
+    // ---- (slot, count) pairs: a few hundred a workgroup, placed one by one
+    for (uint32_t i = threadIdx.x; i < kLogMaxParts; i += kBlock) s_n[1][i] = 0;
+    __syncthreads();
+    const uint32_t n_many = log.n_many[b];
+    const uint2 *many = log.many + (uint64_t)b * kLogMany;
+    for (uint32_t i = threadIdx.x; i < n_many; i += kBlock) atomicAdd(&s_n[1][many[i].x >> log.shift], 1u);
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < P; p += kBlock) {
+        const uint32_t n = s_n[1][p];
+        s_base[1][p] = s_start[1][p] + (n ? atomicAdd(&log.cur[kLogMaxParts + p], n) : 0u);
+        s_n[1][p] = 0;
+    }
+    __syncthreads();
     for (uint32_t i = threadIdx.x; i < n_many; i += kBlock) {
         const uint2 e = many[i];
         const uint32_t p = e.x >> log.shift;
@@ -3106,26 +3231,27 @@ hipError_t launch_scan(hipStream_t s, int W, const uint32_t *rows, const uint16_
 }
 
 template <int M>
-static void launch_dp_m(hipStream_t s, int which, int g, const uint32_t *rows, const uint16_t *lens, int W, const DpParams &dp,
+static void launch_dp_m(hipStream_t s, int which, int g, int W, const DpParams &dp,
                         short2 *spans, BatchLists bl, const uint32_t *list, const uint32_t *cnt, uint32_t count_stat,
                         uint64_t *counters) {
-    if (which == 0) hipLaunchKernelGGL(k_dp<M>, dim3(g), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, list, cnt, count_stat, counters);
+    if (which == 0) hipLaunchKernelGGL(k_dp<M>, dim3(g), dim3(kBlock), 0, s, W, dp, spans, bl, list, cnt, count_stat, counters);
     else {
         // (the class split inside the kernel works for any grid: no more workgroups than the chip holds at once)
         const bool fit = (grid_fit_mask() & 4) != 0;
         static const int occ = occupancy_of(k_dpall<M>, 0);
         const int ga = fit ? std::min(g, 256 * occ) : g;
-        hipLaunchKernelGGL(k_dpall<M>, dim3(ga), dim3(kBlock), 0, s, rows, lens, W, dp, spans, bl, counters);
+        hipLaunchKernelGGL(k_dpall<M>, dim3(ga), dim3(kBlock), 0, s, W, dp, spans, bl, counters);
     }
 }
 
-static hipError_t launch_dp_any(hipStream_t s, int which, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp,
+static hipError_t launch_dp_any(hipStream_t s, int which, int W, const DpParams &dp,
                                 short2 *spans, BatchLists bl, const uint32_t *list, const uint32_t *cnt, uint32_t count_stat,
                                 uint64_t *counters) {
     if (bl.grid == 0) return hipSuccess;
+    if (!bl.rows || !bl.lens || (W != 10 && W != 20 && W != 40)) return hipErrorInvalidValue;
     static const uint32_t g_max = [] { const char *v = getenv("VFIND_DP_GRID"); const int x = v ? atoi(v) : 1024; return (uint32_t)(x >= 64 && x <= (int)kMaxGrid ? x : 1024); }();
     const int g = which == 0 ? (int)(bl.grid < g_max ? bl.grid : g_max) : (int)g_max;
-#define VF_DP_CASE(M) case M: launch_dp_m<M>(s, which, g, rows, lens, W, dp, spans, bl, list, cnt, count_stat, counters); break;
+#define VF_DP_CASE(M) case M: launch_dp_m<M>(s, which, g, W, dp, spans, bl, list, cnt, count_stat, counters); break;
     switch (dp.m) {
         VF_DP_CASE(1) VF_DP_CASE(2) VF_DP_CASE(3) VF_DP_CASE(4) VF_DP_CASE(5) VF_DP_CASE(6) VF_DP_CASE(7) VF_DP_CASE(8)
         VF_DP_CASE(9) VF_DP_CASE(10) VF_DP_CASE(11) VF_DP_CASE(12) VF_DP_CASE(13) VF_DP_CASE(14) VF_DP_CASE(15) VF_DP_CASE(16)
@@ -3138,51 +3264,53 @@ static hipError_t launch_dp_any(hipStream_t s, int which, int W, const uint32_t 
 }
 
 // full-width DP over the role's own list (scoring schemes that give the filter no usable bound)
-hipError_t launch_dp(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
+hipError_t launch_dp(hipStream_t s, int W, const DpParams &dp, short2 *spans,
                      BatchLists bl, uint64_t *counters) {
     const uint32_t *list = dp.is_prefix ? bl.listP : bl.listS;
     const uint32_t *cnt = dp.is_prefix ? bl.cntP : bl.cntS;
-    return launch_dp_any(s, 0, W, rows, lens, dp, spans, bl, list, cnt, 1u, counters);
+    return launch_dp_any(s, 0, W, dp, spans, bl, list, cnt, 1u, counters);
 }
 
 // every task class of the filter's output, one launch
-hipError_t launch_dp_classes(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
+hipError_t launch_dp_classes(hipStream_t s, int W, const DpParams &dp, short2 *spans,
                              BatchLists bl, uint64_t *counters) {
     // (the banded class as a launch of its own, 77 instead of 113 registers per wave, measured the same: 9.48 vs 9.43 G reads/s)
-    return launch_dp_any(s, 1, W, rows, lens, dp, spans, bl, nullptr, nullptr, 0u, counters);
+    return launch_dp_any(s, 1, W, dp, spans, bl, nullptr, nullptr, 0u, counters);
 }
 
-hipError_t launch_filter(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans,
+hipError_t launch_filter(hipStream_t s, int W, const DpParams &dp, short2 *spans,
                          BatchLists bl, uint64_t *counters) {
     if (bl.grid == 0) return hipSuccess;
+    if (!bl.rows || !bl.lens) return hipErrorInvalidValue;
     const int g = (int)bl.grid;                       // one workgroup per list segment (<= kMaxGrid)
     switch (W) {
-    case 10: hipLaunchKernelGGL(k_filter<10>, dim3(g), dim3(kBlock), 0, s, rows, lens, dp, spans, bl, counters); break;
-    case 20: hipLaunchKernelGGL(k_filter<20>, dim3(g), dim3(kBlock), 0, s, rows, lens, dp, spans, bl, counters); break;
-    case 40: hipLaunchKernelGGL(k_filter<40>, dim3(g), dim3(kBlock), 0, s, rows, lens, dp, spans, bl, counters); break;
+    case 10: hipLaunchKernelGGL(k_filter<10>, dim3(g), dim3(kBlock), 0, s, dp, spans, bl, counters); break;
+    case 20: hipLaunchKernelGGL(k_filter<20>, dim3(g), dim3(kBlock), 0, s, dp, spans, bl, counters); break;
+    case 40: hipLaunchKernelGGL(k_filter<40>, dim3(g), dim3(kBlock), 0, s, dp, spans, bl, counters); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
 template <int W>
-static void launch_bmfilter_w(hipStream_t s, int g, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans, BatchLists bl,
+static void launch_bmfilter_w(hipStream_t s, int g, const DpParams &dp, short2 *spans, BatchLists bl,
                               uint64_t *counters) {
     switch (dp.nblk) {
-    case 2: hipLaunchKernelGGL((k_bmfilter<W, 2>), dim3(g), dim3(kBlock), 0, s, rows, lens, dp, spans, bl, counters); break;
-    case 3: hipLaunchKernelGGL((k_bmfilter<W, 3>), dim3(g), dim3(kBlock), 0, s, rows, lens, dp, spans, bl, counters); break;
-    default: hipLaunchKernelGGL((k_bmfilter<W, 4>), dim3(g), dim3(kBlock), 0, s, rows, lens, dp, spans, bl, counters); break;
+    case 2: hipLaunchKernelGGL((k_bmfilter<W, 2>), dim3(g), dim3(kBlock), 0, s, dp, spans, bl, counters); break;
+    case 3: hipLaunchKernelGGL((k_bmfilter<W, 3>), dim3(g), dim3(kBlock), 0, s, dp, spans, bl, counters); break;
+    default: hipLaunchKernelGGL((k_bmfilter<W, 4>), dim3(g), dim3(kBlock), 0, s, dp, spans, bl, counters); break;
     }
 }
-hipError_t launch_bmfilter(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, const DpParams &dp, short2 *spans, BatchLists bl,
+hipError_t launch_bmfilter(hipStream_t s, int W, const DpParams &dp, short2 *spans, BatchLists bl,
                            uint64_t *counters) {
     if (bl.grid == 0) return hipSuccess;
+    if (!bl.rows || !bl.lens) return hipErrorInvalidValue;
     if (dp.nblk < 2 || dp.nblk > 4) return hipErrorInvalidValue;
     const int g = (int)bl.grid;
     switch (W) {
-    case 10: launch_bmfilter_w<10>(s, g, rows, lens, dp, spans, bl, counters); break;
-    case 20: launch_bmfilter_w<20>(s, g, rows, lens, dp, spans, bl, counters); break;
-    case 40: launch_bmfilter_w<40>(s, g, rows, lens, dp, spans, bl, counters); break;
+    case 10: launch_bmfilter_w<10>(s, g, dp, spans, bl, counters); break;
+    case 20: launch_bmfilter_w<20>(s, g, dp, spans, bl, counters); break;
+    case 40: launch_bmfilter_w<40>(s, g, dp, spans, bl, counters); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -3256,7 +3384,7 @@ static void count_log_parts(uint64_t slots, uint64_t n, uint32_t *parts, uint32_
 hipError_t launch_finish(hipStream_t s, int W, const uint32_t *rows, const uint16_t *lens, uint64_t n, const short2 *spans,
                          bool skip_translation, Table t, CountLog log) {
     if (n == 0) return hipSuccess;
-    if (n >> 32) return hipErrorInvalidValue;         // read indices are 32-bit in the work lists
+    if (n >> 31) return hipErrorInvalidValue;         // read indices are 31-bit in the work lists (bit 31 of an entry is a flag)
     hipError_t e = ensure_lut();
     if (e != hipSuccess) return e;
     // one read per lane and trip measured best once the kernel runs two workgroups per CU (7.44 vs 7.23 G reads/s over
