@@ -256,8 +256,8 @@ def end_to_end_leg(vfind_amd, oracle, gen, ads, n_reads, device, slots, host_thr
 def valu_util_from_profiles():
     """per-kernel VALU utilisation from the SQ counter pass committed under profiles/ (scripts/pmc_sq.sh)"""
     try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_sq.json")))
-        return {"source": "profiles/r03_pmc_sq.json", "definition": j.get("definition"),
+        j = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_sq.json")))
+        return {"source": "profiles/r04_pmc_sq.json", "definition": j.get("definition"),
                 "kernels": {k: v.get("valu_util") for k, v in j.get("kernels", {}).items()}}
     except Exception:
         return None
@@ -600,14 +600,15 @@ def main():
         ms_tot, launches, bytes_per_launch, _ = kern[dom]
         avg_ms = ms_tot / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM bytes of the dominant kernel from the PMC passes committed under profiles/ (separate
-        # rocprofv3 --pmc runs of this same workload, gfx950 FETCH_SIZE correction applied there)
+        # memory-side bytes of the dominant kernel per launch, from the single-counter PMC passes committed under profiles/
+        # (scripts/pmc_requests.sh -> profiles/r04_requests.json: TCC_EA0 read requests x their size - all of them 128 B on this
+        # chip, which is what the guide's "FETCH_SIZE halves wide reads" correction amounts to - plus write requests x 64 B)
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_hbm.json")))["kernels"]
-            prefix = {"scan": "vf::k_scan<10", "finish": "vf::k_finish<10"}.get(dom)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_requests.json")))["derived_per_launch"]
+            prefix = {"scan": "k_scan<10", "finish": "k_finish<10"}.get(dom)
             if prefix and L == 150 and n == 10_000_000:
-                traffic = next((v.get("traffic") for k, v in pmc.items() if k.startswith(prefix)), None)
+                traffic = next((int((v["read_MB"] + v["write_MB"]) * 1e6) for k, v in pmc.items() if k.startswith(prefix)), None)
         except Exception:
             traffic = None
         # whole path: wall time per step (two batch lanes overlap, so per-kernel times sum to more than this)

@@ -39,7 +39,7 @@ both = overlap(uc, uk)
 print("# FASTQ path: host-to-device copies against kernels (round 4)")
 print()
 print("\`rocprofv3 --kernel-trace --memory-copy-trace -- python3 scripts/fastq_diag.py $reads $nt\` (scripts/fastq_trace.sh): vf_run_fastq on a multi-member gzip FASTQ of the bench's read model,")
-print("queue_len 4, n_threads $nt; the second (timed) pass of the process.  Run line: " + open("$R/gpurun_out/${tag}_fastq_trace.log").read().strip().splitlines()[-1])
+print("queue_len 4, n_threads $nt; the second (timed) pass of the process.  Run line: " + next((l for l in open("$R/gpurun_out/${tag}_fastq_trace.log").read().splitlines() if l.startswith("fastq_diag:")), "?"))
 print()
 print(f"| span | copies busy (union) | kernels busy (union) | copy time under a kernel | kernel time under a copy |")
 print(f"|---|---|---|---|---|")

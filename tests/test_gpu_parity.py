@@ -1296,3 +1296,39 @@ def test_merge_refuses_byte_keys_a_tagged_table_cannot_hold():
         src.export_to(blob.data_ptr(), blob.numel())
         with pytest.raises(ValueError, match="non-ASCII"):
             dst.merge_from(blob.data_ptr(), n)
+
+
+def test_resident_batch_cut_into_pieces():
+    """VFIND_RES_SPLIT: a resident batch (vf_process_device_packed) cut into pieces that go down the batch lanes one after the
+    other (also what a batch of more than 2^30 reads gets: task entries are 31-bit) - spans of every piece land at their reads'
+    places, the table equals the oracle's, no duplicate entries.  (The switch is read once per process: a child process.)"""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+from vfind_amd import Engine
+from benchlib import synth as vsynth
+from oracle import oracle
+ads = vsynth.adapters(91, 20)
+gen = vsynth.Generator(91, ads, n_variants=30000, sub_rate=0.03, indel_rate=0.004)
+n = 300_000
+rows, lens = gen.packed(0, n, 8)
+data, offs = gen.ascii(0, n, 8)
+d_rows = torch.from_numpy(rows).cuda(); d_lens = torch.from_numpy(lens.view("int16")).cuda()
+d_spans = torch.full((n, 2), -7, dtype=torch.int16, device="cuda")
+with Engine(ads, table_slots=1 << 17) as e:
+    e.process_device(d_rows.data_ptr(), rows.shape[1], d_lens.data_ptr(), n, d_spans.data_ptr())
+    got = e.finish_dict()
+    st = e.stats()
+sp = d_spans.cpu().numpy().astype(np.int64)
+ost, oen = oracle.spans((data, offs), ads, n_threads=8)
+has = ost >= 0
+assert (sp[has, 0] == ost[has]).all() and (sp[has, 1] == np.maximum(oen[has], -1)).all()
+assert (sp != -7).all()                      # every piece wrote its reads' spans
+assert got == oracle.count((data, offs), ads, n_threads=8)
+assert st["dup_rows"] == 0 and st["launches_scan"] == 0 and st["reads"] == n
+print("pieces ok", len(got))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, VFIND_RES_SPLIT="70000"))
+    assert out.returncode == 0 and "pieces ok" in out.stdout, out.stderr[-3000:]

@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libvfind_hip.so")
+SO_PATH = os.environ.get("VFIND_LIB_PATH") or os.path.join(_HERE, "libvfind_hip.so")      # (VFIND_LIB_PATH: another build of the library, A/B runs)
 
 VF_OK, VF_EINVAL, VF_EIO, VF_EFORMAT, VF_EDEVICE, VF_ECAPACITY, VF_ENOMEM = range(7)
 ABI_VERSION = 4          # VF_ABI_VERSION of include/vfind_hip.h

@@ -970,6 +970,9 @@ __global__ __launch_bounds__(kBlock) void k_filter(DpParams dp, short2 *__restri
 // and two FLAT launches (every workgroup an equal share of all tasks through a prefix sum over the segments: 50 + 69 us on
 // one lane, 1.02-1.06 ms per step).
 // ------------------------------------------------------------------------------------------------
+#ifndef VF_BF_GIVE_UP_BELOW
+#define VF_BF_GIVE_UP_BELOW 2     // fifths of a wave's first trip the block filter must classify for the wave to go on with it (0 = always goes on)
+#endif
 // trips of one wave over a task list of the workgroup: lane l of wave w takes tasks w*64 + l + 256 i
 struct TripIter {
     uint32_t t, ntask;
@@ -991,9 +994,21 @@ __device__ __forceinline__ void front_bf_stage(const TaskSrc &src, const DpParam
     uint32_t t = it.t;
     bool v_n = t < ntask;
     uint32_t r_n = v_n ? list[seg0 + t] : 0u;
+    // A wave whose FIRST trip's tasks the block filter mostly cannot classify (a library with many substitutions: at 15 % only
+    // one adapter copy in six has at most one) hands the rest of its tasks to the Myers pass unseen: the block filter's trip -
+    // a row gather and ~800 instructions - only pays when it spares most tasks the Myers pass and gives them the narrow band.
+    // Any class is exact, so the results do not depend on who classifies (VF_BF_GIVE_UP_BELOW: classified share x 5 of the first trip).
+    bool give_up = false;                             // (wave-uniform)
     for (uint32_t i = 0; i < ntrip; ++i, t += kBlock) {
         const uint32_t r = r_n;
         const bool valid = v_n;
+        if (give_up) {
+            v_n = t + kBlock < ntask;
+            r_n = v_n ? list[seg0 + t + kBlock] : 0u;
+            const uint32_t iR = wave_append(&s_c[2], valid);
+            if (valid) cs.listR[seg0 + iR] = r;
+            continue;
+        }
         uint32_t x[W + 2];
         int n = 0;
         if (valid) { n = (int)src.lens[r & kTaskIndexMask]; load_row<W>(src.rows, r & kTaskIndexMask, x); }      // (r: a task entry)
@@ -1013,6 +1028,10 @@ __device__ __forceinline__ void front_bf_stage(const TaskSrc &src, const DpParam
         if (to0) { cs.listW[0][seg0 + i0] = r; cs.winW[0][seg0 + i0] = win; }
         const uint32_t iR = wave_append(&s_c[2], toR);
         if (toR) cs.listR[seg0 + iR] = r;
+        if (i == 0 && VF_BF_GIVE_UP_BELOW > 0) {
+            const uint32_t seen = (uint32_t)__popcll(__ballot(valid)), hit = (uint32_t)__popcll(__ballot(toN || to0));
+            give_up = seen >= 32u && hit * 5u < seen * (uint32_t)VF_BF_GIVE_UP_BELOW;
+        }
     }
 }
 
@@ -2139,6 +2158,82 @@ __device__ __forceinline__ void slot_load_key(const uint4 *p, uint32_t nd, bool 
     a = make_uint4(va.x, va.y, va.z, va.w); b = make_uint4(vb.x, vb.y, vb.z, vb.w);
     c = make_uint4(vc.x, vc.y, vc.z, vc.w); d = make_uint4(vd.x, vd.y, vd.z, vd.w);
 }
+// The one-shot lookup's line loads, two lanes to a line (round 4; built, measured, OFF).  A lane loading the quarters of its own
+// slot line issues one L2 request per 16-byte quarter - 2.25 a lookup for cfg 2's peptides, 11 M of the 20 M L2 requests k_finish
+// makes a step.  Here the wave's 64 lookups are served in two rounds of 32: lanes 2k and 2k + 1 load the first and the second
+// quarter of lookup 32 r + k - 32 bytes next to each other, ONE request - straight into LDS (global_load_lds_dwordx4:
+// destination = M0 + 16 x lane, which is exactly row k of a [32][32 B] image), and every lane then reads its own row back.  The
+// third and fourth quarter (keys of more than 24 letters: a minority) come per lane as before.  Bit-identical (79 device tests),
+// k_finish's L2 requests 20.1 M -> 15.6 M a step - and the step does not move (cfg 2 0.735-0.745 against 0.737-0.746 ms, same
+// box, three rounds; cfg-4 shape +1.5 %, cfg-5 shape -1 %): the request list through LDS, the barrier and the read-back put two
+// LDS round trips in front of and behind every trip's one memory round trip, 132 registers instead of 125, 5.6 KB more LDS.
+// Not every L2 request costs the same (EXPERIMENTS R4.6).
+// req: the wave's {slot, quarters} pairs; img: its [64][32 B] image (2 KiB).  Wave-uniform call.
+#ifndef VF_COOP_LOOKUP
+#define VF_COOP_LOOKUP 0        // (A/B: make variant NAME=coop DEFS=-DVF_COOP_LOOKUP=1)
+#endif
+#if VF_COOP_LOOKUP
+typedef uint32_t u32x2g __attribute__((ext_vector_type(2)));
+struct LookupStage { u32x4 img[WAVE][2]; u32x2g req[WAVE]; };
+__device__ __forceinline__ void slot_load_coop(LookupStage &st, const uint4 *slots, uint32_t slot, uint32_t nd, bool can, uint32_t tag,
+                                               uint4 &a, uint4 &b, uint4 &c, uint4 &d) {
+    const uint32_t lane = lane_id();
+    const uint32_t nq = !can ? 0u : (nd > 10u ? 4u : nd > 6u ? 3u : nd > 2u ? 2u : 1u);
+    *VF_LDS(u32x2g, &st.req[lane]) = u32x2g{slot, nq};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&st.img[0][0]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const u32x2g rq = *VF_LDS(u32x2g, &st.req[32 * r + (lane >> 1)]);
+        const uint32_t h = lane & 1u;
+        const bool act = rq.y > h;                                     // the lookup wants this quarter
+        const uint4 *src = slots + (uint64_t)rq.x * 4 + h;
+        const uint64_t m = __ballot(act);
+        uint64_t save_exec;
+        uint32_t save_m0;
+        asm volatile("s_mov_b64 %0, exec\n\t"
+                     "s_mov_b32 %1, m0\n\t"
+                     "s_mov_b32 m0, %4\n\t"
+                     "s_mov_b64 exec, %3\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %2, off sc1\n\t"
+                     "s_mov_b64 exec, %0\n\t"
+                     "s_mov_b32 m0, %1"
+                     : "=&s"(save_exec), "=&s"(save_m0)
+                     : "v"(src), "s"(m), "s"(lds_base + (uint32_t)r * 1024u)
+                     : "memory");
+    }
+    // quarters three and four: per lane, as slot_load_key does
+    u32x4 vc = {tag, tag, tag, tag}, vd = vc;
+    {
+        const uint4 *p = slots + (uint64_t)slot * 4;
+        const uint64_t m3 = __ballot(nq > 2u), m4 = __ballot(nq > 3u);
+        uint64_t save;
+        asm volatile("s_mov_b64 %2, exec\n\t"
+                     "s_mov_b64 exec, %4\n\t"
+                     "global_load_dwordx4 %0, %3, off offset:32 sc1\n\t"
+                     "s_mov_b64 exec, %5\n\t"
+                     "global_load_dwordx4 %1, %3, off offset:48 sc1\n\t"
+                     "s_mov_b64 exec, %2\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "+v"(vc), "+v"(vd), "=&s"(save)
+                     : "v"(p), "s"(m3), "s"(m4)
+                     : "memory");
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // (a quarter that was not fetched compares as the key's padding: zero, or the epoch pattern in a tagged table)
+    u32x4 va = *VF_LDS(u32x4, &st.img[lane][0]), vb = *VF_LDS(u32x4, &st.img[lane][1]);
+    if (nq < 1u) va = u32x4{0u, 0u, tag, tag};
+    if (nq < 2u) vb = u32x4{tag, tag, tag, tag};
+    a = make_uint4(va.x, va.y, va.z, va.w); b = make_uint4(vb.x, vb.y, vb.z, vb.w);
+    c = make_uint4(vc.x, vc.y, vc.z, vc.w); d = make_uint4(vd.x, vd.y, vd.z, vd.w);
+    __builtin_amdgcn_wave_barrier();                                   // (the image is free for the next call)
+}
+#endif
 struct FastProbe {
     uint32_t slot;
     uint32_t h1, h2, meta;
@@ -2273,9 +2368,19 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
     __shared__ BlockTable bt;
     __shared__ uint32_t s_stat[4];                // accepted, counted, slow, (slot, count) pairs logged
     __shared__ uint32_t s_slow[kBlock / WAVE][kSlowCap];
-#if VF_COOP_STORE
-    __shared__ LineStage s_stage[kBlock / WAVE];
+    // (one wave-private stage for both: a lookup's image is read back before the trip's new lines are staged, and those have left
+    // before the next trip's lookup)
+#if VF_COOP_LOOKUP
+    union WaveStage { LookupStage lookup; LineStage line; };
+#else
+    union WaveStage { LineStage line; };
 #endif
+    __shared__ __attribute__((aligned(16))) unsigned char s_wave_stage[kBlock / WAVE][sizeof(WaveStage)];
+#if VF_COOP_LOOKUP
+    LookupStage &my_lookup = *reinterpret_cast<LookupStage *>(s_wave_stage[threadIdx.x / WAVE]);
+#endif
+    LineStage &my_line = *reinterpret_cast<LineStage *>(s_wave_stage[threadIdx.x / WAVE]);
+    (void)my_line;
     extern __shared__ uint32_t s_tot[];           // [2][kLogMaxParts] log entries per slot part (log.parts != 0 only)
 #ifdef VF_FINISH_PRIO            // A/B: the table kernel's waves issue ahead of the chain kernels' waves on a shared SIMD
     __builtin_amdgcn_s_setprio(VF_FINISH_PRIO);
@@ -2399,7 +2504,11 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
                     for (int u = 0; u < U; ++u) {
                         uint4 a, b, c, d;
                         uint4 *sp = t.slots + (uint64_t)fp[u].slot * 4;
+#if VF_COOP_LOOKUP
+                        slot_load_coop(my_lookup, t.slots, fp[u].slot, fp[u].nd, fp[u].can, FK::kKind == kKindBytes ? t.key_tag : 0u, a, b, c, d);
+#else
                         slot_load_key(sp, fp[u].nd, fp[u].can, FK::kKind == kKindBytes ? t.key_tag : 0u, a, b, c, d);
+#endif
                         found[u] = fast_check(fp[u], a, b, c, d);
                         // A new key whose home slot is empty is inserted right here (letter keys: they validate themselves, so
                         // the claim is READY at once and the line is stored without a wait - table_find_or_insert's selfval
@@ -2416,7 +2525,7 @@ __global__ VF_FINISH_ATTR void k_finish(const uint32_t *__restrict__ rows, const
                                 if (empty) old = atomicCAS(reinterpret_cast<unsigned long long *>(sp), (unsigned long long)w0seen, (unsigned long long)w0claim);
                                 const bool won = empty && old == w0seen;
 #if VF_COOP_STORE
-                                coop_line_store(s_stage[threadIdx.x / WAVE], won, sp, w0claim, fp[u].kin);
+                                coop_line_store(my_line, won, sp, w0claim, fp[u].kin);
 #else
                                 if (won) {
                                     const uint32_t (&kin)[kInlineDwords] = fp[u].kin;
