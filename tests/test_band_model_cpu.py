@@ -102,29 +102,33 @@ def test_wide_band_class_equals_full_dp(monkeypatch):
     assert wrong > 0
 
 
-def test_hamming_certified_band_equals_full_dp():
+def test_hamming_certified_band_equals_full_dp(monkeypatch):
     """round 4 (vf_kernels.hip hamming_band_class): a single-cluster task whose cluster's centre diagonal carries the adapter
     with h substitutions has an optimum of at least match*m - h*(match - mismatch), so its optimal alignments have at most
     kq = max_unit_errors of that bound unit edits and lie on (hi - lo) + 2 kq + 1 diagonals: restated on the CPU against the
     full-matrix DP over random scoring schemes, 2-5 edits, flanks, cut reads, repetitive adapters and second copies - accept /
-    reject, score and length agree; with kq - 1 in the place of kq the model disagrees, so it bites"""
+    reject, score and length agree.  The model bites: with the band two diagonals off it disagrees on ~4 % of the tasks (and with
+    kq - 2 in the place of kq on ~1 %; kq - 1 survives random tasks - the bound has a unit of slack against them - which is why the
+    proof, not the sample, is the argument).  A sample: the tool's 10 000-task run is profiles/r04_band_model_10000.log."""
     rng = random.Random(20261006)
     stats, seen = {}, 0
-    while seen < 1200:
+    while seen < 500:
         good = band_model.hamming_case(rng, stats)
         if good is None:
             continue
         assert good
         seen += 1
-    assert stats.get("accepted", 0) > 1000
-    assert sum(v for k, v in stats.items() if isinstance(k, tuple) and k[0] == band_model.KBAND and k[1] == 2) > 200      # the two-substitution tasks
-    assert sum(v for k, v in stats.items() if isinstance(k, tuple) and k[1] >= 3) > 20
+    assert stats.get("accepted", 0) > 400
+    assert sum(v for k, v in stats.items() if isinstance(k, tuple) and k[0] == band_model.KBAND and k[1] == 2) > 100      # the two-substitution tasks
+    assert sum(v for k, v in stats.items() if isinstance(k, tuple) and k[1] >= 3) > 10
     import contextlib
     import io
+    real = band_model.banded
+    monkeypatch.setattr(band_model, "banded", lambda q, r, av, *a: real(q, r, av + 2, *a))
     wrong = seen = 0
     with contextlib.redirect_stdout(io.StringIO()):
-        while seen < 700:
-            good = band_model.hamming_case(rng, kq_shift=1)
+        while seen < 250:
+            good = band_model.hamming_case(rng)
             if good is None:
                 continue
             seen += 1

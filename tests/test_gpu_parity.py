@@ -1191,6 +1191,25 @@ def test_rccl_entry_points_single_rank():
             e.comm_init(2, 2, uid)
 
 
+def test_rccl_transport_walks_the_whole_exchange_with_one_rank(monkeypatch):
+    """RcclTransport itself - ncclAllGather of the status words, ncclGroupStart / ncclGroupEnd rounds, the polled waits with
+    ncclCommGetAsyncError - through vf_table_allreduce with a one-rank communicator (test hook VFIND_TEST_ALLREDUCE_SINGLE; RCCL
+    refuses two ranks on one GPU): the table goes through bucket export, clear, merge and share export and comes out as it was.
+    And a deadline that cannot be met ends in an error and an aborted communicator, not in a hang."""
+    from vfind_amd import Engine
+    reads = synth.make_reads(521, 6000, AD20, L=150, n_variants=700)
+    want = oracle.count(reads, AD20)
+    monkeypatch.setenv("VFIND_TEST_ALLREDUCE_SINGLE", "1")
+    with Engine(AD20, table_slots=1 << 12) as e:
+        e.submit(reads)
+        e.comm_init(0, 1, Engine.comm_unique_id())
+        e.allreduce_rccl(0)
+        assert e.finish_dict() == want
+        e.allreduce_rccl(0)                                    # the communicator is reusable
+        assert e.finish_dict() == want
+        assert e.stats()["dup_rows"] == 0
+
+
 def test_pinned_batch_api_round_trips_the_slots():
     """vf_batch_acquire / vf_batch_submit: the caller packs straight into the library's page-locked staging; one thread walks
     round the queue_len slots (acquire hands out the slot used longest ago), results equal the oracle, an acquired batch can be

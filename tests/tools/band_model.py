@@ -404,7 +404,7 @@ def hamming_decision(ad, read, T, kerr, match, mismatch, gopen, gext, k_lo=None,
     kq = max_unit_errors(T2, m, match, mismatch, gopen, gext)
     if kq is None or not (1 <= kq < kerr):
         return None
-    kq_used = kq - kq_shift                                  # (kq_shift = 1: the test that shows the model bites)
+    kq_used = kq - kq_shift                                  # (kq_shift > 0: a deliberately wrong bound, to see the model bite)
     if kq_used < 1:
         return None
     dl = kerr - kq_used
