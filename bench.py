@@ -284,7 +284,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the legs beside the headline: result build, PCIe-inclusive, end-to-end FASTQ, tie-sensitive fraction")
     ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the two gzip FASTQ files of the end-to-end leg (BASELINE configs[2] in shape)")
     ap.add_argument("--other-config-reads", type=int, default=8_000_000, help="resident reads per step of each of the other BASELINE shapes (extras)")
-    ap.add_argument("--other-config-parity-reads", type=int, default=2_000_000, help="reads of those shapes whose whole table is compared with the CPU oracle")
+    ap.add_argument("--other-config-parity-reads", type=int, default=4_000_000, help="reads of those shapes whose whole table is compared with the CPU oracle")
     ap.add_argument("--merge-transport", default="auto", choices=["auto", "rccl", "torch"],
                     help="final table reduce: rccl = the library's own exchange (vf_comm_init / vf_table_allreduce), torch = the same "
                          "algorithm with torch.distributed moving the bytes; auto = rccl when the backend is nccl")

@@ -3358,7 +3358,7 @@ static hipError_t launch_dp_any(hipStream_t s, int which, int W, const DpParams 
                                 uint64_t *counters) {
     if (bl.grid == 0) return hipSuccess;
     if (!bl.rows || !bl.lens || (W != 10 && W != 20 && W != 40)) return hipErrorInvalidValue;
-    static const uint32_t g_max = [] { const char *v = getenv("VFIND_DP_GRID"); const int x = v ? atoi(v) : 1024; return (uint32_t)(x >= 64 && x <= (int)kMaxGrid ? x : 1024); }();
+    static const uint32_t g_max = [] { const char *v = getenv("VFIND_DP_GRID"); const int x = v ? atoi(v) : 768; return (uint32_t)(x >= 64 && x <= (int)kMaxGrid ? x : 768); }();      // (three workgroups a CU: round 4, same box, three rounds: cfg 2 0.787-0.790 against 0.799-0.807 ms at 1024, cfg-5 shape -3 %, cfg-4 shape level; 512 and below lose)
     const int g = which == 0 ? (int)(bl.grid < g_max ? bl.grid : g_max) : (int)g_max;
 #define VF_DP_CASE(M) case M: launch_dp_m<M>(s, which, g, W, dp, spans, bl, list, cnt, count_stat, counters); break;
     switch (dp.m) {
