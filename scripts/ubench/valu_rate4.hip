@@ -6,7 +6,7 @@
 __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 __device__ __forceinline__ uint32_t to_vgpr_u(uint32_t s) { uint32_t v; asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v; }
 
-// OP 0: scan stage 1 as in vf_kernels.hip (4 shifts, 8 bases, 2 adapters), data in registers
+// OP 0: scan stage 1 as in vf_k_front.hip (4 shifts, 8 bases, 2 adapters), data in registers
 // OP 1: the same without the funnel shifts (bitop3 only)
 // OP 2: only the funnel shifts
 template <int OP>

@@ -77,7 +77,7 @@ def test_block_model_detects_a_band_that_is_too_narrow(monkeypatch):
 
 
 def test_wide_band_class_equals_full_dp(monkeypatch):
-    """class 6 of the Myers filter (vf_kernels.hip, kBandW): a task whose detected end columns form ONE cluster [jmin, jmax]
+    """class 6 of the Myers filter (vf_kernels_common.h kBandW, vf_k_front.hip myers_classify): a task whose detected end columns form ONE cluster [jmin, jmax]
     with jmax - jmin + 2 kerr + 1 <= 16 runs the banded DP on the diagonals [jmin - m - kerr, jmax - m + kerr], whatever its
     edits.  Restated on the CPU against the full-matrix DP: accept / reject, score and length agree; and the model bites -
     a band placed with kerr - 1 in the place of kerr loses alignments"""
@@ -103,7 +103,7 @@ def test_wide_band_class_equals_full_dp(monkeypatch):
 
 
 def test_hamming_certified_band_equals_full_dp(monkeypatch):
-    """round 4 (vf_kernels.hip hamming_band_class): a single-cluster task whose cluster's centre diagonal carries the adapter
+    """round 4 (vf_k_front.hip hamming_band_class): a single-cluster task whose cluster's centre diagonal carries the adapter
     with h substitutions has an optimum of at least match*m - h*(match - mismatch), so its optimal alignments have at most
     kq = max_unit_errors of that bound unit edits and lie on (hi - lo) + 2 kq + 1 diagonals: restated on the CPU against the
     full-matrix DP over random scoring schemes, 2-5 edits, flanks, cut reads, repetitive adapters and second copies - accept /

@@ -98,7 +98,7 @@ def test_exact_scan_decoys(m):
     pre, suf = rand(m), rand(m)
     while suf == pre:
         suf = rand(m)
-    # bases stage 1 looks at (vf_kernels.hip scan_plan): pairs (b, b+16) while the adapter is longer than 16 + b, then singles
+    # bases stage 1 looks at (vf_k_front.hip scan_plan): pairs (b, b+16) while the adapter is longer than 16 + b, then singles
     pairs = max(0, min(4, m - 16))
     singles = max(0, min(8 - 2 * pairs, min(m, 16) - pairs))
     checked = set(range(pairs + singles)) | {b + 16 for b in range(pairs)}

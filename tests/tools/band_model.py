@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""CPU model of the filter's class-0 decision and of the banded DP (dp_banded, vf_kernels.hip), checked against the
+"""CPU model of the filter's class-0 decision and of the banded DP (dp_banded, vf_k_dp.hip), checked against the
 full-matrix DP of oracle/pyref.py on random tasks.  No GPU: it restates the kernel's control flow (relative
 columns, rows per column, what a cell reads outside the band) in Python, so the argument of DESIGN.md 4.3
 (tightened edit bound, shrunk cluster, band of diagonals) is tested on its own.
@@ -369,7 +369,7 @@ def wide_case(rng, stats=None):
 # The adapter laid on the cluster's centre diagonal(s) differs from the read in h bases: an ungapped alignment of score
 # match*m - h*(match - mismatch), hence S* >= T'' = max(T, that) and every optimal alignment has at most
 # kq = max_unit_errors(T'') unit edits.  End columns of optimal alignments lie kerr - kq inside the cluster, their cells on
-# [lo - m - kq, hi - m + kq] (vf_kernels.hip, hamming_band_class / myers_classify).
+# [lo - m - kq, hi - m + kq] (vf_k_front.hip, hamming_band_class / myers_classify).
 def hamming_decision(ad, read, T, kerr, match, mismatch, gopen, gext, k_lo=None, kq_shift=0):
     """the Myers pass's class decision for one task as myers_classify makes it, restricted to what the certificate adds:
     returns None (the certificate does not apply / the task is class 0 by the d <= 1 rule already) or (band width, av, h, kq)"""

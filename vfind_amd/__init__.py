@@ -3,7 +3,7 @@
 Host-side mirror of the reference's only public interface, the PyO3 function `find_variants`
 (reference: src/lib.rs:168-232), over the C ABI of include/vfind_hip.h.  The per-read work --
 adapter match, semi-global alignment fallback, extraction, translation, counting -- runs in
-hand-written HIP kernels (vfind_amd/csrc/vf_kernels.hip); there is no CPU fallback.
+hand-written HIP kernels (vfind_amd/csrc/vf_k_*.hip); there is no CPU fallback.
 """
 from __future__ import annotations
 

@@ -1,5 +1,5 @@
 // vf_device.h -- structures shared by the host runtime (vf_host.cpp) and the gfx950 kernels
-// (vf_kernels.hip).  Internal; the public boundary is include/vfind_hip.h.
+// (vf_k_*.hip).  Internal; the public boundary is include/vfind_hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -70,7 +70,7 @@ struct GenericParams {
 };
 
 // ---- device count table ---------------------------------------------------------------------
-// Open addressing, linear probing, one 64-byte slot per key (layout and protocol: vf_kernels.hip).
+// Open addressing, linear probing, one 64-byte slot per key (layout and protocol: vf_table_dev.h).
 // Exported entries: ref = key_off_dwords<<24 | 1<<23 | kind<<16 | len  (len: bytes for kind 0, bases
 // for kind 1), keys compacted into the blob arena.
 constexpr uint64_t kRefValid = 1ull << 23;
@@ -115,7 +115,7 @@ struct Table {
     // every key dword of a live letter key carries the epoch in the top bits of its four bytes (letters are ASCII: those bits
     // are free) - key_tag = the pattern.  vf_table_clear then bumps the epoch instead of zeroing the slot lines (128 MB of the
     // 151 MB a clear of a 2^21-slot table wrote; 2 GB at 2^25 slots): stale lines read as free slots, stale key dwords as
-    // "not written yet".  Every 15th clear zeroes for real (the epoch wraps).  vf_kernels.hip, "Epoch tags".
+    // "not written yet".  Every 15th clear zeroes for real (the epoch wraps).  vf_table_dev.h, "Epoch tags".
     uint32_t epoch, key_tag;
 };
 constexpr uint32_t kTagBits = 0x80808080u;
@@ -136,7 +136,7 @@ inline uint32_t key_tag_of(uint32_t epoch) {
 // with one atomic), k_log_apply gives every range of kLogRange slots to one workgroup, which counts its part's entries
 // in LDS and adds what it has to the 64-bit counts, contiguous, once.  parts == 0: k_log_direct adds entry by entry
 // (tables so large that a batch touches few of their ranges).
-constexpr uint32_t kLogMany = 1024 + 256;   // pairs a workgroup can leave: aggregator + key cache entries (vf_kernels.hip)
+constexpr uint32_t kLogMany = 1024 + 256;   // pairs a workgroup can leave: aggregator + key cache entries (vf_table_dev.h)
 #ifndef VF_LOG_MAX_PARTS
 #define VF_LOG_MAX_PARTS 256
 #endif
@@ -157,11 +157,11 @@ struct CountLog {
 uint64_t count_log_entries(uint64_t n_reads, int W, bool dna, uint32_t *grid, uint32_t *cap_one);   // geometry of launch_finish for n reads
 uint64_t count_log_entries_max(uint64_t n_reads, uint32_t *grid_max);                              // ... over every row width and key kind
 
-// ---- launchers (vf_kernels.hip) ---------------------------------------------------------------
+// ---- launchers (vf_k_*.hip) ------------------------------------------------------------------
 struct BatchLists {        // per in-flight batch; lists are segmented per workgroup of k_scan
     const uint32_t *rows;             // the batch itself: the filter and DP stages gather their tasks' rows and lengths from it
     const uint16_t *lens;
-    uint32_t *listP, *listS;          // DP tasks per adapter (grid*seg entries each): read index | suffix-pending flag << 31 (vf_kernels.hip, "Task entries")
+    uint32_t *listP, *listS;          // DP tasks per adapter (grid*seg entries each): read index | suffix-pending flag << 31 (vf_kernels_common.h, "Task entries")
     uint32_t *listW[4], *winW[4];     // filter output by class: 0 banded (+ first diagonal + kBandBias), 1..3 windowed (+ window a | b<<16)
     uint32_t *winW2;                  // second window of class-3 (two-window) tasks
     uint32_t *listF;                  // filter output: tasks only the full-width DP can take

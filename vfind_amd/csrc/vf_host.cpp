@@ -4,7 +4,7 @@
 // host threads into pinned staging, the per-GPU batch pipeline (hipMemcpyAsync of batch k+1
 // overlapped with the kernels of batch k on per-slot streams), the device count table, and the
 // result build (lib.rs:312-319).  No CPU fallback exists: every per-read decision is made by the
-// kernels in vf_kernels.hip; the host only decodes, packs, launches and formats.
+// kernels in vf_k_*.hip; the host only decodes, packs, launches and formats.
 #include "../../include/vfind_hip.h"
 #include "vf_device.h"
 #include "vf_internal.h"
@@ -2003,7 +2003,7 @@ static int vf_finish_impl(vf_ctx *c, vf_result **out) {
     const auto t0 = std::chrono::steady_clock::now();
     if ((rc = vf_table_export(c, blob.p, nbytes, nullptr))) return rc;
     // the row set of the DataFrame (lib.rs:312-316) is built on the device (vf_result.hip): strings expanded, duplicate
-    // strings summed (possible only if the device saw a stale table word, see vf_kernels.hip:table_add), rows ordered by
+    // strings summed (possible only if the device saw a stale table word, see vf_table_dev.h:table_add), rows ordered by
     // count descending then sequence ascending; only the three finished buffers come back
     uint64_t hdr[2];
     HIP_TRY(hipMemcpy(hdr, blob.p, 16, hipMemcpyDeviceToHost));
