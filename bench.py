@@ -624,7 +624,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(bytes_per_launch),
-                         "events": ("inside the timed region" + (", on every 3rd step's launch (a bracket costs the step ~2 %)" if ev_mode == 3 else "")) if (dom in ("finish", "scan") or ev_mode == 1) else "pass after the timed region",
+                         "events": ("inside the timed region" + (", on every 3rd step's launch (the brackets cost the window ~1 %: EXPERIMENTS R4.10)" if ev_mode == 3 else "")) if (dom in ("finish", "scan") or ev_mode == 1) else "pass after the timed region",
                          "launches_timed": int(launches)},
             "roofline_path": {"bound": "hbm", "achieved": round(path_gbps, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": round(path_gbps / HBM_PEAK_GBPS, 6), "alg_bytes_per_read": b_alg(L),

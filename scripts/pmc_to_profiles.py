@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/r02_pmc_sq.json from a `scripts/pmc_sq.sh` pass (rocprofv3 --kernel-trace --pmc SQ_* of bench.py, one batch lane).
-usage: pmc_to_profiles.py counter_collection.csv kernel_trace.csv out.json"""
+usage: pmc_to_profiles.py counter_collection.csv kernel_trace.csv out.json [cfg4|cfg5: the shape scripts/cfg_shape.py ran]"""
 import collections
 import csv
 import json
@@ -45,5 +45,8 @@ for k, cs in sorted(acc.items()):
         e["wait_frac"] = round(m.get("SQ_WAIT_ANY", 0) / m["SQ_WAVE_CYCLES"], 4)
         e["active_frac"] = round(m.get("SQ_ACTIVE_INST_ANY", 0) / m["SQ_WAVE_CYCLES"], 4)
     out["kernels"][k] = e
+if len(sys.argv) > 4 and sys.argv[4]:
+    out["method"] = out["method"].replace("python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-extras",
+                                          f"python3 scripts/cfg_shape.py {sys.argv[4]} (8 M resident reads a step, 1 warm-up + 10 steps)")
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: (v.get("avg_us"), v.get("valu_util"), v.get("wait_frac")) for k, v in out["kernels"].items()}, indent=1))

@@ -623,7 +623,9 @@ struct Timed {
     // ones: both decided per call (several threads may submit; a shared flag switched one batch's brackets from another's)
     Timed(vf_ctx *c_, hipStream_t s_, int k, int mode, bool sampled) : c(c_), s(s_), kind(k), on(mode == 1 || ((mode == 2 || (mode == 3 && sampled)) && (k == K_FIN || k == K_SCAN))) {
         if (on) {
-            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            // timing only: nothing synchronizes-with these events, so they carry no system-scope fence (hip_runtime_api.h recommends it
+            // for events that only measure: a default record writes the caches back; EXPERIMENTS R4.10: no difference measured here)
+            if (hipEventCreateWithFlags(&a, hipEventDisableSystemFence) != hipSuccess || hipEventCreateWithFlags(&b, hipEventDisableSystemFence) != hipSuccess) { on = false; return; }
             (void)hipEventRecord(a, s);
         }
     }
@@ -814,7 +816,8 @@ static int run_packed(vf_ctx *c, hipStream_t st, uint32_t chunk_row, Workspace &
     // every third batch: an odd period, so that the sampled batches alternate between the two batch lanes (every fourth sat on
     // one lane, always in the same phase against the other lane's k_finish: k_scan 0.515 ms against 0.43-0.47 over all launches)
     const int pmode = c->profiling.load();
-    const bool psample = pmode == 3 && c->prof_batch.fetch_add(1) % 3u == 0u;
+    static const uint32_t prof_period = [] { const char *e = getenv("VFIND_PROF_PERIOD"); const long v = e ? atol(e) : 3; return (uint32_t)(v < 1 ? 1 : v); }();
+    const bool psample = pmode == 3 && c->prof_batch.fetch_add(1) % prof_period == 0u;
     BatchLists bl{};
     bl.rows = d_rows; bl.lens = d_lens;
     bl.listP = ws.listP.p; bl.listS = ws.listS.p; bl.listF = ws.listF.p;
