@@ -134,3 +134,65 @@ def test_hamming_certified_band_equals_full_dp(monkeypatch):
             seen += 1
             wrong += not good
     assert wrong > 0
+
+
+def test_indel_scan_bit_parallel_equals_the_recurrence():
+    """round 4 (vf_k_front.hip indel_column / myers_scan<W, true>): the two-lattice bit-parallel scan gives the indel-distance
+    search row C[m][j] of the plain recurrence - adapters of every length 1..32, reads with planted noisy copies, two- and
+    four-letter alphabets (long runs of equal deltas are where a carry chain would break)"""
+    rng = random.Random(20261007)
+    for it in range(1500):
+        m = rng.randint(1, 32)
+        k = 2 if it % 3 == 0 else 4
+        ad = [rng.randrange(k) for _ in range(m)]
+        cp = list(ad)
+        for _ in range(rng.randint(0, 5)):
+            p = rng.randrange(len(cp)) if cp else 0
+            t = rng.random()
+            if t < 0.4 and cp:
+                cp[p] = rng.randrange(k)
+            elif t < 0.7 and cp:
+                del cp[p]
+            else:
+                cp.insert(p, rng.randrange(k))
+        if it % 4 == 0:
+            cp = []
+        read = [rng.randrange(k) for _ in range(rng.randint(0, 20))] + cp + [rng.randrange(k) for _ in range(rng.randint(0, 40))]
+        read = read or [0]
+        assert band_model.indel_last_row_bitparallel(ad, read) == band_model.indel_last_row(ad, read)
+
+
+def test_indel_scan_never_turns_an_acceptable_task_away():
+    """the filter property ("the indel scan"): under every scheme for which the host picks the indel scan, an
+    alignment the full-matrix DP accepts ends in a column with C <= kthr = max_indel_units(T).  Random schemes, 0-5 edits
+    (substitutions, insertion runs, deletions), cut reads; the check bites with a threshold one unit short; and the scan does
+    turn away tasks the unit-distance scan would have sent to the DP (what it is for)"""
+    rng = random.Random(20261008)
+    stats, seen = {}, 0
+    while seen < 1200:
+        good = band_model.scan_case(rng, stats)
+        if good is None:
+            continue
+        assert good
+        seen += 1
+    assert stats.get("accepted", 0) > 300 and stats.get("rejected", 0) > 300
+    assert stats.get("turned away (the unit scan would have passed it on)", 0) > 20
+    import contextlib
+    import io
+    wrong = seen = 0
+    with contextlib.redirect_stdout(io.StringIO()):
+        while seen < 600:
+            good = band_model.scan_case(rng, None, 1)
+            if good is None:
+                continue
+            seen += 1
+            wrong += not good
+    assert wrong > 0
+
+
+def test_host_bounds_of_the_default_scheme():
+    """vfind's defaults (3 / -2 / 5 / 2, accept 0.75, 20 bp adapter: T = 46, loss <= 14): five unit edits (a five-base insertion)
+    and five indel units (the same, or a substitution and a three-base insertion); three substitutions are 6 > 5"""
+    assert band_model.max_unit_errors(46, 20, 3, -2, 5, 2) == 5
+    assert band_model.max_indel_units(46, 20, 3, -2, 5, 2) == 5
+    assert band_model.max_indel_units(55, 20, 3, -2, 5, 2) == 2 and band_model.max_indel_units(50, 20, 3, -2, 5, 2) == 4

@@ -48,6 +48,97 @@ def myers_last_row(q, r):
     return out
 
 
+def max_indel_units(T, m, match, mismatch, gopen, gext):
+    """host: max_indel_units (vf_host.cpp) - the most INDEL units (a mismatch counts two) an alignment with score >= T can have;
+    -1 nothing reaches T, None no (useful) bound"""
+    L = match * m - T
+    if L < 0:
+        return -1
+    if match < 1 or match - mismatch < 1 or gext < 1 or gopen < 1 or L > 2048:
+        return None
+    csub = match - mismatch
+    c1 = min(match, min(gopen, gext) + match)
+    fill = []
+    for R in range(L + 1):
+        b, sub = 0, 0
+        while sub * csub <= R:
+            b = max(b, 2 * sub + (R - sub * csub) // c1)
+            sub += 1
+        fill.append(b)
+    best = fill[L]
+    g = 1
+    while g * gopen <= L:
+        ln = g
+        while g * gopen + (ln - g) * gext <= L:
+            best = max(best, ln + fill[L - g * gopen - (ln - g) * gext])
+            ln += 1
+        g += 1
+    return best
+
+
+def indel_last_row(q, r):
+    """C[m][j], j = 0..n, of the indel-distance search (free start in the read): the plain recurrence"""
+    m, n = len(q), len(r)
+    prev = list(range(m + 1))
+    out = [m]
+    for j in range(1, n + 1):
+        cur = [0] * (m + 1)
+        for i in range(1, m + 1):
+            cur[i] = prev[i - 1] if q[i - 1] == r[j - 1] else 1 + min(prev[i], cur[i - 1])
+        out.append(cur[m])
+        prev = cur
+    return out
+
+
+def indel_last_row_bitparallel(q, r):
+    """the kernel's two-lattice scan (vf_k_front.hip, indel_column / myers_scan<W, true>), 32-bit words, adapter in the top m bits"""
+    m = len(q)
+    up = 32 - m
+    M32 = 0xFFFFFFFF
+    eq = [0, 0, 0, 0]
+    for i, c in enumerate(q):
+        eq[c] |= 1 << (up + i)
+    na = [0, 0]                                  # ~A of the even / odd lattice
+    out = [m]
+    for j in range(1, len(r) + 1):
+        E = eq[r[j - 1]]
+        best = None
+        for lat in (0, 1):
+            c0 = (j + lat) & 1                   # C[0][j] of the lattice; it steps up into this column <=> c0 == 1
+            P = ~(na[lat] | E) & M32
+            sm = ((P | na[lat]) + na[lat] + c0) & M32
+            na[lat] = sm & ~P & M32
+            C = c0 + m - 2 * bin(na[lat]).count("1")
+            best = C if best is None else min(best, C)
+        out.append(best)
+    return out
+
+
+METRIC = "auto"        # "unit": always the Myers scan; "auto": the indel scan where its bound is no larger than kerr (host: fill_dp)
+
+
+class Scan:
+    """what the pre-DP scan of one task sees, in the metric the host picks for the scheme: D[j] per end column, the threshold
+    kthr, and shrink(T_tight, k_unit) = how far inside a cluster the end columns of alignments scoring >= T_tight lie"""
+    def __init__(self, ad, read, T, kerr, match, mismatch, gopen, gext):
+        m = len(ad)
+        self.args = (m, match, mismatch, gopen, gext)
+        ki = max_indel_units(T, m, match, mismatch, gopen, gext) if METRIC == "auto" else None
+        self.indel = ki is not None and 1 <= ki <= kerr
+        if self.indel:
+            self.D, self.kthr = indel_last_row(ad, read), ki
+        else:
+            self.D, self.kthr = myers_last_row(ad, read), kerr
+        self.kerr = kerr
+
+    def shrink(self, T_tight, k_unit):
+        if not self.indel:
+            return self.kerr - k_unit
+        m, match, mismatch, gopen, gext = self.args
+        k = max_indel_units(T_tight, m, match, mismatch, gopen, gext)
+        return self.kthr - k if (k is not None and 0 <= k <= self.kthr) else 0
+
+
 def clusters(det_cols, gap):
     ncl, c = 0, [0, 0, 0, 0]
     for j in det_cols:
@@ -150,14 +241,15 @@ def one_case(rng):
     k_lo = max_unit_errors(T_lo, m, match, mismatch, gopen, gext)
     if k_lo is None or not (1 <= k_lo < kerr):
         return None
-    D = myers_last_row(ad, read)
-    det = [j for j in range(1, n + 1) if D[j] <= kerr]
+    sc = Scan(ad, read, T, kerr, match, mismatch, gopen, gext)
+    D = sc.D
+    det = [j for j in range(1, n + 1) if D[j] <= sc.kthr]
     ncl, c = clusters(det, m + kerr)
     own = 4 * (n // 4)
     dmin = min(D[1: own + 1]) if own else m
     if not (dmin <= 1 and ncl == 1):
         return None
-    dl = kerr - k_lo
+    dl = sc.shrink(T_lo, k_lo)
     lo = c[0] + dl if c[0] > 1 else 1
     hi = c[1] - dl if c[1] < n else n
     if not (hi >= lo and hi - lo + 2 * k_lo + 1 <= KBAND):
@@ -308,6 +400,7 @@ def block_case(rng, stats=None):
 # KBAND_W the task is a banded one, whatever its edits are (no certified column of distance <= 1 is needed: the bound is the
 # plain kerr, not the tightened one).  15 % substitutions put nearly every task here instead of into a 64-column window.
 KBAND_W = 16
+KHAM_DIAGS = 12
 
 
 def wide_case(rng, stats=None):
@@ -342,8 +435,9 @@ def wide_case(rng, stats=None):
     kerr = max_unit_errors(T, m, match, mismatch, gopen, gext)
     if kerr is None or kerr < 1 or m + kerr > 48:
         return None
-    D = myers_last_row(ad, read)
-    det = [j for j in range(1, n + 1) if D[j] <= kerr]
+    sc = Scan(ad, read, T, kerr, match, mismatch, gopen, gext)
+    D = sc.D
+    det = [j for j in range(1, n + 1) if D[j] <= sc.kthr]
     if not det:
         return None
     ncl, c = clusters(det, m + kerr)
@@ -374,8 +468,9 @@ def hamming_decision(ad, read, T, kerr, match, mismatch, gopen, gext, k_lo=None,
     """the Myers pass's class decision for one task as myers_classify makes it, restricted to what the certificate adds:
     returns None (the certificate does not apply / the task is class 0 by the d <= 1 rule already) or (band width, av, h, kq)"""
     m, n = len(ad), len(read)
-    D = myers_last_row(ad, read)
-    det = [j for j in range(1, n + 1) if D[j] <= kerr]
+    sc = Scan(ad, read, T, kerr, match, mismatch, gopen, gext)
+    D = sc.D
+    det = [j for j in range(1, n + 1) if D[j] <= sc.kthr]
     if not det:
         return None
     ncl, c = clusters(det, m + kerr)
@@ -385,16 +480,20 @@ def hamming_decision(ad, read, T, kerr, match, mismatch, gopen, gext, k_lo=None,
     own = 4 * (n // 4)
     dmin = min(D[1: own + 1]) if own else m
     if k_lo is not None and dmin <= 1:                       # class 0 by the tightened bound of a d <= 1 column (one_case covers it)
-        dl = kerr - k_lo
+        c_max = max(match, match - mismatch, match + max(gopen, gext))
+        dl = sc.shrink(max(T, match * m - c_max), k_lo)
         lo = jmin + dl if jmin > 1 else 1
         hi = jmax - dl if jmax < n else n
         if hi >= lo and hi - lo + 2 * k_lo + 1 <= KBAND:
             return None
     hmin = None
-    for e in (0, 1):
-        jc = (jmin + jmax + e) >> 1
+    j0, cnt = jmin, jmax - jmin + 1
+    if cnt > KHAM_DIAGS:                                     # the centre-most diagonals of a wide cluster
+        j0 += (cnt - KHAM_DIAGS) >> 1
+        cnt = KHAM_DIAGS
+    for jc in range(j0, j0 + cnt):
         d = jc - m
-        if d < 0 or jc > n:
+        if d < 0 or jc > n or d - max(j0 - m, 0) >= KHAM_DIAGS:
             continue
         h = sum(a != b for a, b in zip(ad, read[d:d + m]))
         hmin = h if hmin is None else min(hmin, h)
@@ -407,7 +506,7 @@ def hamming_decision(ad, read, T, kerr, match, mismatch, gopen, gext, k_lo=None,
     kq_used = kq - kq_shift                                  # (kq_shift > 0: a deliberately wrong bound, to see the model bite)
     if kq_used < 1:
         return None
-    dl = kerr - kq_used
+    dl = sc.shrink(T2, kq) + kq_shift
     lo = jmin + dl if jmin > 1 else 1
     hi = jmax - dl if jmax < n else n
     if hi < lo:
@@ -486,6 +585,63 @@ def hamming_case(rng, stats=None, kq_shift=0):
     if not good:
         print("MISMATCH (Hamming certificate)", dict(match=match, mismatch=mismatch, gopen=gopen, gext=gext, T=T, kerr=kerr, h=h, kq=kq, av=av, kband=kband),
               qb, rb, "full", (fs, fl), "band", (bs, bl))
+    return good
+
+
+# ---- the indel scan (round 4): the filter itself ---------------------------------------------------------------------------------
+def scan_case(rng, stats=None, units_shift=0):
+    """one random task under a scheme for which the host picks the indel scan: True/False = (the kernel's two-lattice scan equals
+    the plain recurrence) and (an alignment the full-matrix DP accepts ends in a column the scan detects: C <= kthr there);
+    None = the scheme keeps the unit scan.  units_shift > 0: a threshold that much too small, to see the check bite"""
+    match = rng.choice([1, 2, 3, 3, 3, 4, 5])
+    mismatch = rng.choice([-4, -3, -2, -2, -2, -1, 0])
+    gopen = rng.choice([1, 2, 3, 5, 5, 5, 8])
+    gext = rng.choice([1, 2, 2, 2, 3, 4])
+    m = rng.randint(4, 32)
+    acc = rng.choice([0.5, 0.6, 0.7, 0.75, 0.75, 0.8, 0.9])
+    T = int(acc * match * m // 1) + 1
+    ad = [rng.randrange(4) for _ in range(m)]
+    cp = list(ad)
+    for _ in range(rng.choice([0, 1, 1, 2, 2, 3, 3, 4, 5])):
+        t = rng.random()
+        p = rng.randrange(len(cp))
+        if t < 0.5:
+            cp[p] = (cp[p] + rng.randint(1, 3)) % 4
+        elif t < 0.8:
+            for _ in range(rng.choice([1, 1, 2, 3, 5])):
+                cp.insert(p, rng.randrange(4))
+        elif len(cp) > 3:
+            del cp[p:p + rng.choice([1, 1, 2])]
+    flank = [rng.randrange(4) for _ in range(rng.choice([0, 0, 1, 2, 5, 9, 17, 40]))]
+    tail = [rng.randrange(4) for _ in range(rng.choice([0, 0, 1, 2, 3, 7, 20, 60]))]
+    read = flank + cp + tail
+    if rng.random() < 0.3:
+        read = read[rng.randint(1, 6):]
+    if rng.random() < 0.3:
+        read = read[: len(read) - rng.randint(1, 6)]
+    n = len(read)
+    if n == 0:
+        return None
+    kerr = max_unit_errors(T, m, match, mismatch, gopen, gext)
+    if kerr is None or kerr < 1 or m + kerr > 48:
+        return None
+    sc = Scan(ad, read, T, kerr, match, mismatch, gopen, gext)
+    if not sc.indel:
+        return None
+    good = indel_last_row_bitparallel(ad, read) == sc.D
+    letters = b"ACGT"
+    qb = bytes(letters[x] for x in ad)
+    rb = bytes(letters[x] for x in read)
+    fs, fl, bq, bd = pyref.sg_stats_py(qb, rb, match, mismatch, gopen, gext)
+    if stats is not None:
+        stats["accepted" if fs >= T else "rejected"] = stats.get("accepted" if fs >= T else "rejected", 0) + 1
+        if fs < T and min(sc.D[1:]) > sc.kthr >= min(myers_last_row(ad, read)[1:]) - 0 and min(myers_last_row(ad, read)[1:]) <= kerr:
+            stats["turned away (the unit scan would have passed it on)"] = stats.get("turned away (the unit scan would have passed it on)", 0) + 1
+    if fs >= T and sc.D[bd] > sc.kthr - units_shift:
+        good = False
+    if not good:
+        print("MISMATCH (indel scan)", dict(match=match, mismatch=mismatch, gopen=gopen, gext=gext, T=T, kerr=kerr, kthr=sc.kthr), qb, rb,
+              "full", (fs, fl, bq, bd), "C", sc.D[bd])
     return good
 
 

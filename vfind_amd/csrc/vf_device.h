@@ -49,6 +49,15 @@ struct DpParams {
     // has a diagonal at Hamming distance h (max_unit_errors of max(T, match*m - h*(match - mismatch))), -1 where that is no
     // tighter than kerr; kerr_h[0] = 1 if any entry is set (0 = certificate off)
     int32_t kerr_h[8];
+    // The pre-DP scan's metric (vf_k_front.hip, myers_scan): indel = 0 unit edit distance (Myers), threshold kthr = kerr; indel = 1 indel
+    // distance (a mismatch = 2 units), threshold kthr = the most indel units an acceptable alignment can have (host: max_indel_units),
+    // chosen where that is no larger than kerr.  eq_top's low 32-m bits are ones for the unit scan and zeros for the indel scan.
+    // dl_lo / dl_h[h]: how many columns inside the cluster of detected columns the end columns of OPTIMAL alignments lie under the
+    // tightened bounds kerr_lo / kerr_h[h] - kthr minus the tightened bound in the scan's own units (0 = no shrink)
+    uint32_t indel;
+    int32_t kthr;
+    int32_t dl_lo;
+    int32_t dl_h[8];
 };
 
 struct ScanParams {

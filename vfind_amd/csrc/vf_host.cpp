@@ -337,6 +337,29 @@ static int32_t max_unit_errors(int64_t T, size_t m, int32_t match, int32_t misma
     return best > 1000000 ? INT32_MAX : (int32_t)best;
 }
 
+// The same bound in INDEL units (a mismatch counts two: a deletion and an insertion), for the indel scan of the pre-DP filter:
+// the most such units an alignment with score >= T can contain.  A mismatch loses match-mismatch for 2 units, any other single
+// unit (unaligned adapter end base, adapter base in a gap) at least min(match, min(open,ext)+match), read bases in g gaps of
+// total length len lose g*open + (len-g)*ext for len units.  -1: nothing reaches T; INT32_MAX: no (useful) bound.
+static int32_t max_indel_units(int64_t T, size_t m, int32_t match, int32_t mismatch, int32_t gopen, int32_t gext) {
+    const int64_t L = (int64_t)match * (int64_t)m - T;
+    if (L < 0) return -1;
+    if (match < 1 || match - mismatch < 1 || gext < 1 || gopen < 1 || L > 2048) return INT32_MAX;
+    const int64_t csub = (int64_t)match - mismatch;
+    const int64_t c1 = std::min<int64_t>(match, std::min(gopen, gext) + (int64_t)match);
+    std::vector<int64_t> fill((size_t)L + 1);              // fill[R]: mismatches and other single units within a loss of R
+    for (int64_t R = 0; R <= L; ++R) {
+        int64_t b = 0;
+        for (int64_t s = 0; s * csub <= R; ++s) b = std::max(b, 2 * s + (R - s * csub) / c1);
+        fill[(size_t)R] = b;
+    }
+    int64_t best = fill[(size_t)L];
+    for (int64_t g = 1; g * gopen <= L; ++g)
+        for (int64_t len = g; g * gopen + (len - g) * gext <= L; ++len)
+            best = std::max(best, len + fill[(size_t)(L - g * gopen - (len - g) * gext)]);
+    return best > 1000000 ? INT32_MAX : (int32_t)best;
+}
+
 static void fill_dp(DpParams &d, const std::string &ad, int64_t T, const vf_ctx &c, bool is_prefix) {
     d.pat = pack_adapter(ad);
     d.m = (uint32_t)ad.size();
@@ -391,8 +414,32 @@ static void fill_dp(DpParams &d, const std::string &ad, int64_t T, const vf_ctx 
             if (k_h >= 1 && k_h < d.kerr) { d.kerr_h[h] = k_h; d.kerr_h[0] = 1; }
         }
     }
+    // the scan's metric: indel distance where its bound is no weaker than the unit bound (VFIND_INDEL_SCAN=0: never; A/B)
+    static const bool indel_ok = [] { const char *e = getenv("VFIND_INDEL_SCAN"); return !(e && !atoi(e)); }();
+    d.indel = 0; d.kthr = d.kerr;
+    d.dl_lo = d.kerr_lo >= 0 ? d.kerr - d.kerr_lo : 0;
+    for (int h = 0; h < 8; ++h) d.dl_h[h] = (h && d.kerr_h[h] >= 0) ? d.kerr - d.kerr_h[h] : 0;
+    if (indel_ok && d.kerr >= 1 && d.kerr != INT32_MAX) {
+        const int32_t ki = max_indel_units(T, ad.size(), c.match, c.mismatch, c.gopen, c.gext);
+        if (ki >= 1 && ki <= d.kerr) {
+            d.indel = 1; d.kthr = ki;
+            auto shrink = [&](int64_t T_tight) {            // kthr minus the bound under the tightened threshold, in indel units
+                const int32_t k = max_indel_units(T_tight, ad.size(), c.match, c.mismatch, c.gopen, c.gext);
+                return (k >= 0 && k <= ki) ? ki - k : 0;
+            };
+            if (d.kerr_lo >= 0) {
+                const int64_t c_max = std::max<int64_t>(std::max<int64_t>(c.match, (int64_t)c.match - c.mismatch),
+                                                        (int64_t)c.match + std::max(c.gopen, c.gext));
+                d.dl_lo = shrink(std::max<int64_t>(T, (int64_t)c.match * (int64_t)ad.size() - c_max));
+            }
+            for (int h = 1; h < 8; ++h)
+                if (d.kerr_h[h] >= 0)
+                    d.dl_h[h] = shrink(std::max<int64_t>(T, (int64_t)c.match * (int64_t)ad.size() - (int64_t)h * ((int64_t)c.match - c.mismatch)));
+        }
+    }
     const uint32_t up = 32u - d.m;                     // d.m in 1..32
-    for (int q = 0; q < 4; ++q) d.eq_top[q] = up ? ((d.eq[q] << up) | ((1u << up) - 1u)) : d.eq[q];
+    const uint32_t filler = (up && !d.indel) ? ((1u << up) - 1u) : 0u;
+    for (int q = 0; q < 4; ++q) d.eq_top[q] = up ? ((d.eq[q] << up) | filler) : d.eq[q];
     d.pv_init = up ? (0xFFFFFFFFu << up) : 0xFFFFFFFFu;
 }
 

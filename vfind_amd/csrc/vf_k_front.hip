@@ -222,6 +222,30 @@ __device__ __forceinline__ void myers_column(uint32_t Eq, uint32_t &Pv, uint32_t
     Mv = Ph & Xv;
 }
 
+// The same scan under INDEL distance (a mismatch = a deletion + an insertion = 2 units; round 4, DESIGN.md 4.3 "the indel scan").
+// An acceptable alignment also has a bounded number of INDEL units (host: max_indel_units - the same knapsack with a
+// substitution worth two), and where that bound is no larger than kerr the indel scan is the sharper filter at the same price:
+// a copy with three substitutions has unit distance 3 but indel distance 6, and the scoring schemes that accept a five-base
+// insertion (loss open + 4 ext) reject three substitutions (loss 3 (match - mismatch)).  At the cfg-4 shape (15 % substitutions)
+// more than half of the tasks the unit-distance scan passed on were such copies: DP work that always ended in a rejection.
+//
+// Under indel distance neighbouring cells differ by exactly +-1 once the boundary is consistent, which the free-start row
+// C[0][j] = 0 is not.  So the scan runs TWO lattices and takes the smaller value: sources restricted to even read positions
+// (C[0][j] = j mod 2) and to odd ones (C[0][j] = (j + 1) mod 2; its phantom source before the read costs one unit more than
+// the even lattice's source at 0 and never wins).  In each lattice, with a_i = the vertical step C[i][j-1] - C[i-1][j-1] and
+// h_i = the horizontal step C[i][j] - C[i][j-1] (both +-1):  match: h_i = -a_i, v_i = -h_{i-1};  mismatch, a_i = -1: h_i = +1,
+// v_i = -h_{i-1};  mismatch, a_i = +1: h_i = h_{i-1}, v_i = +1.  With A = {a_i = +1} that is a carry chain - generate ~A,
+// propagate P = A & ~E - which ONE addition resolves: s = (~A | P) + ~A + h_0, carry into row i = s_i ^ P_i, and the new
+// ~A is s & ~P.  State: nA = ~A per lattice (filler bits below the adapter: A = 1, E = 0, they hand the boundary step h_0 up to
+// the first row).  C[m][j] = C[0][j] + m - 2 popcount(nA): one v_bcnt gives the detection.  5 instructions a lattice and
+// column, 14 a column with the bookkeeping, against Myers' 15.  tests/tools/band_model.py restates it against the plain
+// recurrence (indel_last_row); tests/test_band_model_cpu.py::test_indel_scan_bit_parallel_equals_the_recurrence.
+template <uint32_t CIN> __device__ __forceinline__ void indel_column(uint32_t E, uint32_t &nA) {
+    const uint32_t P = ~(nA | E);
+    const uint32_t s = (P | nA) + nA + CIN;
+    nA = s & ~P;
+}
+
 // s_eq2[16]: entry (b0 | b1<<2) = {Eq[b0], Eq[b1]}: one 8-byte LDS read serves two columns.
 // Every lane of the wave runs the same number of 16-column words (the longest read's); columns past a
 // lane's own read are computed on the row's zero padding and masked out of the detections, so the
@@ -239,12 +263,20 @@ __device__ __forceinline__ void myers_first_chunk(const uint32_t *__restrict__ r
         xn[2 * i] = v.x; xn[2 * i + 1] = v.y;
     }
 }
-template <int W>
+template <int W, bool INDEL>
 __device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int n, const DpParams &dp, const uint2 *s_eq2,
                                            Clusters &cl, uint32_t (&xn)[10]) {
     constexpr int CW = 10;                             // words per chunk (xn holds chunk 0 on entry)
     uint32_t Pv = dp.pv_init, Mv = 0u;
-    int sc = (int)dp.m - dp.kerr - 1;                  // unit edit distance minus (kerr + 1): negative <=> detected
+    int sc = (int)dp.m - dp.kthr - 1;                  // unit edit distance minus (kthr + 1): negative <=> detected
+    // indel scan: ~A of the even / odd lattice; a column is detected where popcount(nA) >= Q(C[0][j]), Q(c) = ceil((c + m - kthr) / 2);
+    // w = popcount - Q per lattice and column, wmax0 / wmax1 its maximum over the cells with C[0][j] = 0 / 1 (-> dmin)
+    uint32_t nAe = 0u, nAo = 0u;
+    const int Q0 = ((int)dp.m - dp.kthr + 1) >> 1, Q1 = ((int)dp.m - dp.kthr + 2) >> 1;
+    uint32_t negQ0, negQ1;                             // (VGPRs: a VALU instruction with an SGPR operand issues at half rate)
+    asm("v_mov_b32 %0, %1" : "=v"(negQ0) : "s"(-Q0));
+    asm("v_mov_b32 %0, %1" : "=v"(negQ1) : "s"(-Q1));
+    int wmax0 = -Q0, wmax1 = -Q1, wown0 = -Q0, wown1 = -Q1;
     const int gap = (int)dp.m + dp.kerr;
     cl.ncl = 0; cl.jmin1 = 0; cl.jmax1 = 0; cl.jmin2 = 0; cl.jmax2 = 0;
     // running minimum of sc over every column computed, and its value at the last 4-column boundary inside the
@@ -289,11 +321,29 @@ __device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int
                 uint2 e[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) e[q] = eq_pair(q == 0 ? (word << 3) & 0x78u : (word >> (4 * q - 3)) & 0x78u);
+                if constexpr (!INDEL) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    myers_column(e[q].x, Pv, Mv, sc); det = funnel(det, (uint32_t)sc, 31); smin = min(smin, sc);
-                    myers_column(e[q].y, Pv, Mv, sc); det = funnel(det, (uint32_t)sc, 31); smin = min(smin, sc);
-                    if (q & 1) smin_own = 16 * w + 2 * (q + 1) <= n ? smin : smin_own;
+                    for (int q = 0; q < 8; ++q) {
+                        myers_column(e[q].x, Pv, Mv, sc); det = funnel(det, (uint32_t)sc, 31); smin = min(smin, sc);
+                        myers_column(e[q].y, Pv, Mv, sc); det = funnel(det, (uint32_t)sc, 31); smin = min(smin, sc);
+                        if (q & 1) smin_own = 16 * w + 2 * (q + 1) <= n ? smin : smin_own;
+                    }
+                } else {
+                    asm volatile("" : "+v"(nAe), "+v"(nAo));
+                    uint32_t nd = 0;                   // one NOT-detected bit per column (the sign of w in both lattices)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        // column 16 w + 2 q + 1 (odd): C[0][j] = 1 in the even lattice (it steps up: carry in), 0 in the odd one
+                        indel_column<1u>(e[q].x, nAe); indel_column<0u>(e[q].x, nAo);
+                        int we = (int)__builtin_popcount(nAe) + (int)negQ1, wo = (int)__builtin_popcount(nAo) + (int)negQ0;
+                        nd = funnel(nd, (uint32_t)(we & wo), 31); wmax1 = max(wmax1, we); wmax0 = max(wmax0, wo);
+                        // column 16 w + 2 q + 2 (even): the other way round
+                        indel_column<0u>(e[q].y, nAe); indel_column<1u>(e[q].y, nAo);
+                        we = (int)__builtin_popcount(nAe) + (int)negQ0; wo = (int)__builtin_popcount(nAo) + (int)negQ1;
+                        nd = funnel(nd, (uint32_t)(we & wo), 31); wmax0 = max(wmax0, we); wmax1 = max(wmax1, wo);
+                        if (q & 1) { const bool own = 16 * w + 2 * (q + 1) <= n; wown0 = own ? wmax0 : wown0; wown1 = own ? wmax1 : wown1; }
+                    }
+                    det = ~nd;
                 }
                 // bit 15-k <=> column 16w+k+1; only the lane's own columns count
                 const int kmax = min(16, n - 16 * w);
@@ -312,7 +362,15 @@ __device__ __forceinline__ void myers_scan(const uint32_t *__restrict__ row, int
             }
         }
     }
-    cl.dmin = smin_own + dp.kerr + 1;
+    if constexpr (!INDEL) cl.dmin = smin_own + dp.kthr + 1;
+    else cl.dmin = min((int)dp.m - 2 * (wown0 + Q0), (int)dp.m + 1 - 2 * (wown1 + Q1));
+}
+// the scan the host chose for this adapter's scoring scheme (wave-uniform)
+template <int W>
+__device__ __forceinline__ void filter_scan(const uint32_t *__restrict__ row, int n, const DpParams &dp, const uint2 *s_eq2,
+                                            Clusters &cl, uint32_t (&xn)[10]) {
+    if (dp.indel) myers_scan<W, true>(row, n, dp, s_eq2, cl, xn);
+    else myers_scan<W, false>(row, n, dp, s_eq2, cl, xn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -450,13 +508,15 @@ __device__ __forceinline__ bool wide_band_class(const Clusters &cl, const DpPara
 
 // ------------------------------------------------------------------------------------------------
 // The Hamming certificate (round 4): classes 0 / 6 for single-cluster tasks with TWO OR MORE substitutions.
-// Lay the adapter on the cluster's centre diagonal(s) - end column jc = (jmin + jmax) / 2, read bases [jc - m, jc) - and count
-// the bases that differ: h.  That ungapped alignment scores match*m - h*(match - mismatch), so the task's optimum is
+// Lay the adapter on a diagonal that ends in a column of the cluster - read bases [j - m, j), every j of the cluster (the
+// kHamDiags centre-most of a wider one): a copy whose substitution sits in the adapter's last rows has a lopsided cluster (cutting
+// those rows off is as cheap, in units, as the substitution) and its diagonal is not the centre one - and count the bases that
+// differ; h = the smallest count.  That ungapped alignment scores match*m - h*(match - mismatch), so the task's optimum is
 // S* >= T'' = max(T, that), and every OPTIMAL alignment has at most kq = max_unit_errors(T'') unit edits (host: fill_dp,
 // dp.kerr_h[h]; kq >= h, so the certified column itself has D <= h <= kq).  The rest is the class-0 argument with kq in the
 // place of kerr_lo: end columns of optimal alignments have D <= kq, D moves by at most one per column, so
-// they lie kerr - kq columns inside the cluster [jmin, jmax] of columns with D <= kerr on every side the read does not cut
-// off: [lo, hi]; alignments with at most kq gap or overhang bases ending there stay on the diagonals
+// they lie kerr - kq columns (dp.dl_h[h]: the same difference in the scan's own units) inside the cluster [jmin, jmax] of
+// columns with D <= kerr on every side the read does not cut off: [lo, hi]; alignments with at most kq gap or overhang bases ending there stay on the diagonals
 // [lo - m - kq, hi - m + kq].  A copy with two substitutions (defaults, m = 20: T'' = 50, kq = 3, cluster 7 columns wide)
 // gets 2 + 6 + 1 = 9 diagonals - class 0 - where the plain bound kerr = 5 gave 6 + 10 + 1 = 17 > kBandW and the task took a
 // 64-column window (546 k of the 1.72 M prefix tasks per 2 M reads of the cfg-4 shape, 70 % of that pass's DP cells).
@@ -468,31 +528,41 @@ __device__ __forceinline__ void hamming_band_class(const uint32_t *__restrict__ 
     if (!__any(cand)) return;
     const int m = (int)dp.m;
     const uint64_t patmask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
+    // every diagonal that ends in a column of the cluster, the kHamDiags centre-most if there are more: a window of the read that
+    // slides by one base a step (three funnel shifts), not a gather per diagonal
+    int j0 = cl.jmin1, cnt = cl.jmax1 - cl.jmin1 + 1;
+    if (cnt > kHamDiags) { j0 += (cnt - kHamDiags) >> 1; cnt = kHamDiags; }
+    const int dA = j0 - m;                             // first diagonal asked for (negative: the adapter would start left of the read)
+    const int dS = cand ? max(dA, 0) : 0;              // first diagonal looked at
+    const int idx = dS >> 4;
+    const uint32_t bsh = 2u * (uint32_t)(dS & 15);
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    if (cand) {
+        w0 = idx < W ? row[idx] : 0u;
+        w1 = idx + 1 < W ? row[idx + 1] : 0u;
+        w2 = idx + 2 < W ? row[idx + 2] : 0u;
+        w3 = idx + 3 < W ? row[idx + 3] : 0u;
+    }
+    uint32_t a0 = funnel(w1, w0, bsh), a1 = funnel(w2, w1, bsh), a2 = funnel(w3, w2, bsh);      // read bases dS .. dS + 47
+    const int dlast = dA + cnt - 1;
     int hmin = 64;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int jc = (cl.jmin1 + cl.jmax1 + e) >> 1;
-        const int d = jc - m;
-        const bool fits = cand && d >= 0 && jc <= n;           // the whole adapter lies inside the read on this diagonal
-        const int idx = fits ? d >> 4 : 0;
-        const uint32_t bsh = 2u * (uint32_t)((fits ? d : 0) & 15);
-        uint32_t d0 = 0, d1 = 0, d2 = 0;
-        if (fits) {
-            d0 = row[idx];
-            d1 = idx + 1 < W ? row[idx + 1] : 0u;
-            d2 = idx + 2 < W ? row[idx + 2] : 0u;
-        }
-        const uint32_t lo = funnel(d1, d0, bsh), hi = funnel(d2, d1, bsh);
-        uint64_t diff = ((((uint64_t)hi << 32) | lo) ^ dp.pat) & patmask;
+    for (int k = 0; k < kHamDiags; ++k) {
+        const int d = dS + k;
+        const bool fits = cand && d <= dlast && d + m <= n;       // asked for, and the whole adapter lies inside the read on it
+        uint64_t diff = ((((uint64_t)a1 << 32) | a0) ^ dp.pat) & patmask;
         diff = (diff | (diff >> 1)) & 0x5555555555555555ull;
-        const int h = fits ? (int)__popcll(diff) : 64;
-        hmin = min(hmin, h);
+        const int h = (int)__popcll(diff);
+        hmin = fits ? min(hmin, h) : hmin;
+        a0 = funnel(a1, a0, 2); a1 = funnel(a2, a1, 2); a2 >>= 2;
     }
     int kq = -1;
 #pragma unroll
     for (int h = 1; h < 8; ++h) kq = hmin == h ? dp.kerr_h[h] : kq;
     if (!cand || kq < 1 || kq >= dp.kerr) return;
-    const int dl = dp.kerr - kq;
+    int dl = 0;                                        // how far inside the cluster the end columns of optimal alignments lie (host: fill_dp)
+#pragma unroll
+    for (int h = 1; h < 8; ++h) dl = hmin == h ? dp.dl_h[h] : dl;
     const int lo = cl.jmin1 > 1 ? cl.jmin1 + dl : 1;
     const int hi = cl.jmax1 < n ? cl.jmax1 - dl : n;
     if (hi < lo) return;
@@ -517,7 +587,7 @@ __device__ __forceinline__ void myers_classify(const uint32_t *__restrict__ row,
     // those alignments lie on the diagonals j - i in [lo - m - kerr_lo, hi - m + kerr_lo]: class 0 when
     // that band is at most kBand wide.
     if (dp.kerr_lo >= 0 && cl.dmin <= 1 && cl.ncl == 1) {
-        const int dl = dp.kerr - dp.kerr_lo;
+        const int dl = dp.dl_lo;
         const int lo = cl.jmin1 > 1 ? cl.jmin1 + dl : 1;
         const int hi = cl.jmax1 < n ? cl.jmax1 - dl : n;
         if (hi >= lo && hi - lo + 2 * dp.kerr_lo + 1 <= kBand) { cls = 0; av = lo - (int)dp.m - dp.kerr_lo; }
@@ -552,7 +622,7 @@ __global__ __launch_bounds__(kBlock) void k_filter(DpParams dp, short2 *__restri
             Clusters cl;
             uint32_t x0[10];
             myers_first_chunk(task_row(src, r), n, x0);
-            myers_scan<W>(task_row(src, r), n, dp, s_eq2, cl, x0);
+            filter_scan<W>(task_row(src, r), n, dp, s_eq2, cl, x0);
             const bool any = valid && cl.ncl > 0;
             if (valid && !any) (void)dp_commit(true, task_head(src, r), false, 0, dp, spans);      // (the header again: nothing of it is kept across the scan)
             int cls, av, a1, a2;
@@ -687,7 +757,7 @@ __device__ __forceinline__ void front_myers_stage(const TaskSrc &src, const DpPa
         v_n = t + kBlock < nR;
         r_n = v_n ? cs.listR[seg0 + t + kBlock] : 0u;
         Clusters cl;
-        myers_scan<W>(task_row(src, r), n, dp, s_eq2, cl, x0);
+        filter_scan<W>(task_row(src, r), n, dp, s_eq2, cl, x0);
         const bool any = valid && cl.ncl > 0;
         if (valid && !any) (void)dp_commit(true, task_head(src, r), false, 0, dp, spans);      // (the header again: nothing of it is kept across the scan)
         int cls, av, a1, a2;

@@ -200,6 +200,7 @@ constexpr int kBandN = 5;        // ... and for the narrow class of the block fi
 #define VF_BAND_W 16          // (A/B: make variant NAME=bw20 DEFS=-DVF_BAND_W=20)
 #endif
 constexpr int kBandW = VF_BAND_W;
+constexpr int kHamDiags = 12;     // diagonals the Hamming certificate lays the adapter on (hamming_band_class)
 constexpr int kBandBias = 4096;  // class-0 window word = first diagonal + kBandBias
 #ifndef VF_HAMMING_CERT
 #define VF_HAMMING_CERT 1       // (A/B: make variant NAME=noham DEFS=-DVF_HAMMING_CERT=0)
