@@ -345,6 +345,81 @@ def test_hamming_certified_band_two_substitution_tasks():
         _check_counts(rd, AD20)
 
 
+def test_indel_scan_at_its_threshold():
+    """Round 4: the pre-DP scan measures indel distance where the scoring scheme allows (a mismatch = 2 units; myers_scan<W, true>,
+    DESIGN.md 4.3 "the indel scan").  The alignments that DEFINE its threshold - at the defaults five units: a five-base insertion,
+    a substitution and a three-base insertion, two two-base insertions, three unaligned end bases and a substitution, one and two
+    substitutions - and the ones just beyond it (a six-base insertion, three substitutions, a substitution and a four-base
+    insertion), at every position of both adapters, at the read start and end, behind flanks of every length mod 16; schemes for
+    which the host keeps the unit scan (cheap substitutions) and schemes that change the threshold; spans against the oracle's
+    full DP.  Interior three-substitution copies - what the scan is there to turn away - are rejected, by it or by the DP"""
+    rng = np.random.default_rng(20261009)
+    R = lambda k: synth.rand_seq(rng, k).decode()
+    other = lambda c: "ACGT"[("ACGT".index(c) + 1 + int(rng.integers(0, 3))) % 4]
+
+    def sub(a, p):
+        return a[:p] + other(a[p]) + a[p + 1:]
+    for ads in (AD20, ("GATCGGAAGAGCACACGTCTGAACTCCAGT", "AGATCGGAAGAGCGTCGTGTAGGGAAAGAG"), ("ACGGTCATGCATT", "TTGCAAGCGTACG")):
+        P, S = ads
+        reads = []
+        for ad, is_p in ((P, True), (S, False)):
+            m = len(ad)
+            oth = S if is_p else P
+            k = 0
+
+            def put(e):
+                nonlocal k
+                flank, tail = k % 17, (0, 1, 3, 6, 2, 0, 9)[(k // 17) % 7]
+                k += 1
+                reads.append(R(flank) + e + R(30 + tail) + oth if is_p else oth + R(33) + R(flank) + e + R(tail))
+            for q in range(1, m):
+                for g in (3, 4, 5, 6):
+                    put(ad[:q] + R(g) + ad[q:])                                   # one insertion run
+                    p = int(rng.integers(0, m))
+                    put(sub(ad, p)[:q] + R(g - 2 if g > 3 else g) + sub(ad, p)[q:])   # a substitution and a run
+                q2 = int(rng.integers(1, m))
+                a, b = sorted((q, q2))
+                put(ad[:a] + R(2) + ad[a:b] + R(2) + ad[b:])                       # two runs
+                put(ad[:a] + R(1) + ad[a:b] + R(3) + ad[b:])
+                put(ad[:q] + ad[q + 1:])                                          # deletions
+                put(sub(ad, (q + 3) % m)[:q] + sub(ad, (q + 3) % m)[q + 1:])
+                if q + 2 <= m:
+                    put(ad[:q] + ad[q + 2:])
+            for u in (1, 2, 3, 4, 5):                                             # unaligned end bases (+ substitutions)
+                for t in range(6):
+                    e = ad
+                    for _ in range(t % 3):
+                        e = sub(e, int(rng.integers(u, m - u)))
+                    reads.append(e[u:] + R(40) + oth if is_p else oth + R(40) + e[: m - u])
+            for t in range(80):                                                    # three substitutions away from the ends
+                pos = sorted(rng.choice(np.arange(2, m - 2), size=3, replace=False).tolist())
+                e = ad
+                for p in pos:
+                    e = sub(e, p)
+                put(e)
+        reads = [r.encode() for r in reads]
+        for kw in (dict(), dict(accept_prefix_alignment=0.6, accept_suffix_alignment=0.85),
+                   dict(match_score=2, mismatch_score=-1, gap_open_penalty=3, gap_extend_penalty=1, accept_prefix_alignment=0.6, accept_suffix_alignment=0.6),
+                   dict(match_score=1, mismatch_score=0, gap_open_penalty=4, gap_extend_penalty=2, accept_prefix_alignment=0.7, accept_suffix_alignment=0.7),
+                   dict(match_score=5, mismatch_score=-4, gap_open_penalty=2, gap_extend_penalty=1, accept_prefix_alignment=0.7, accept_suffix_alignment=0.6),
+                   dict(match_score=4, mismatch_score=-4, gap_open_penalty=8, gap_extend_penalty=4, accept_prefix_alignment=0.5, accept_suffix_alignment=0.5)):
+            _check_spans(reads, ads, **kw)
+        _check_counts(reads, ads)
+    # three substitutions in the adapter's interior, flanks on both sides: the scheme rejects every one of them (loss 15 > 14); the
+    # unit-distance scan sent every one to the DP (distance 3 <= 5), the indel scan those whose rows happen to line up one column off
+    # (59 % in the CPU model; the class histogram of profiles/r04_cfg4_kernel_trace.md shows what is left)
+    P, S = AD20
+    reads = []
+    for t in range(4000):
+        pos = sorted(rng.choice(np.arange(2, 18), size=3, replace=False).tolist())
+        e = P
+        for p in pos:
+            e = sub(e, p)
+        reads.append((R(12 + t % 9) + e + R(60) + S + R(10)).encode())
+    st, en = _check_spans(reads, AD20)
+    assert (st < 0).mean() > 0.99              # (next to none of them has a prefix: rejected by the scan or by the DP, as the oracle's full DP does)
+
+
 @pytest.mark.parametrize("name,kw", [
     ("cfg2", dict(seed=0x5EED0002, read_len=150, m=20, sub_rate=0.005, indel_rate=0.0005)),
     ("cfg4", dict(seed=0x5EED0004, read_len=150, m=20, sub_rate=0.15, indel_rate=0.0)),
