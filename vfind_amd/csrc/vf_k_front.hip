@@ -786,8 +786,13 @@ __device__ __forceinline__ void front_myers_stage(const TaskSrc &src, const DpPa
 // k_bmfilter: block filter and Myers pass of ONE adapter in one launch: a workgroup takes a
 // task segment through the block filter, then its rest through the Myers filter -- one launch and one tail per adapter
 // instead of two, the rest list never leaves the workgroup.
+#ifndef VF_BMF_MINBLOCKS
+#define VF_BMF_ATTR __launch_bounds__(kBlock)
+#else
+#define VF_BMF_ATTR __launch_bounds__(kBlock, (W == 10 ? VF_BMF_MINBLOCKS : 1))     // A/B: register cap for the 150 bp instances (5 -> 96 registers: five waves a SIMD)
+#endif
 template <int W, int NB>
-__global__ __launch_bounds__(kBlock) void k_bmfilter(DpParams dp,
+__global__ VF_BMF_ATTR void k_bmfilter(DpParams dp,
                                                      short2 *__restrict__ spans, BatchLists bl, uint64_t *__restrict__ counters) {
     const TaskSrc src{bl.rows, bl.lens, W};
     __shared__ uint32_t s_bf[3];
