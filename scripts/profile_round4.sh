@@ -6,5 +6,7 @@ PASS_TIMEOUT=200 bash $R/scripts/pmc_requests.sh ${tag}_req TCC_REQ_sum TCC_EA0_
 python3 $R/scripts/pmc_requests_json.py $R/gpurun_out/${tag}_requests.json $R/gpurun_out/${tag}_req/summary.txt
 bash $R/scripts/profile_cfg.sh $tag cfg4 > /dev/null 2>&1
 bash $R/scripts/profile_cfg.sh $tag cfg5 > /dev/null 2>&1
+bash $R/scripts/pmc_sq.sh ${tag}_cfg4_pmc_sq cfg4 > $R/gpurun_out/${tag}_cfg4_pmc_sq.txt 2>&1
+bash $R/scripts/pmc_sq.sh ${tag}_cfg5_pmc_sq cfg5 > $R/gpurun_out/${tag}_cfg5_pmc_sq.txt 2>&1
 bash $R/scripts/fastq_trace.sh $tag 8000000 16 > $R/gpurun_out/${tag}_fastq_trace_run.log 2>&1
 ls -la $R/gpurun_out/${tag}_*
