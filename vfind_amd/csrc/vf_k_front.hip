@@ -21,6 +21,9 @@ __device__ __forceinline__ uint32_t to_vgpr_u(uint32_t s) {
     asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
     return v;
 }
+// (one v_bitop3 per accumulated base: (x ^ b) | acc.  Left to itself the optimiser pairs the terms of the straight-line form
+// into two XORs and a v_or3 - three instructions for two bases)
+#define VF_KEEP(x) asm volatile("" : "+v"(x))
 struct ScanPlan { int nlo, nhi; };                      // bases b < nlo and b+16 for b < nhi are checked
 __device__ __forceinline__ ScanPlan scan_plan(int m) {
     const int pairs = max(0, min(4, m - 16));
@@ -65,16 +68,19 @@ template <int W> __device__ __forceinline__ bool verify_at(const uint32_t *row, 
     return diff == 0ull;
 }
 
-template <int W>
+// P44: both adapters are 20 bases or longer, i.e. both plans are {4, 4} (four pairs, no singles): the stage-1 loop is then
+// straight-line code.  With the plans read at run time it is sixteen wave-uniform branches a trip whose conditions the
+// compiler keeps as 64-bit masks - more than the SGPR file holds, so ~70 v_readlane a trip fetch them back from a VGPR.
+template <int W, bool P44>
 __device__ __forceinline__ void exact_find2(const uint32_t (&r)[W + 2], const uint32_t *row, int n, const ScanParams &sp,
                                             int &ps, int &ss) {
     uint32_t accP[W], accS[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) { accP[w] = 0; accS[w] = 0; }
     const int mp = (int)sp.pre_len, ms = (int)sp.suf_len;
-    const ScanPlan pp = scan_plan(mp), sq = scan_plan(ms);
+    const ScanPlan pp = P44 ? ScanPlan{4, 4} : scan_plan(mp), sq = P44 ? ScanPlan{4, 4} : scan_plan(ms);
 #pragma unroll
-    for (int b = 0; b < 16; ++b) {
+    for (int b = 0; b < (P44 ? 4 : 16); ++b) {
         const bool p0 = b < pp.nlo, p1 = b < pp.nhi, s0 = b < sq.nlo, s1 = b < sq.nhi;       // wave-uniform
         if (p0 || s0) {
             uint32_t xs[W + 1];
@@ -83,22 +89,22 @@ __device__ __forceinline__ void exact_find2(const uint32_t (&r)[W + 2], const ui
             if (p0) {
                 const uint32_t bp = to_vgpr_u((uint32_t)((sp.pre_pat >> (2 * b)) & 3ull) * 0x55555555u);
 #pragma unroll
-                for (int w = 0; w < W; ++w) accP[w] |= xs[w] ^ bp;
+                for (int w = 0; w < W; ++w) { accP[w] |= xs[w] ^ bp; VF_KEEP(accP[w]); }
             }
             if (p1) {
                 const uint32_t bp = to_vgpr_u((uint32_t)((sp.pre_pat >> (2 * b + 32)) & 3ull) * 0x55555555u);
 #pragma unroll
-                for (int w = 0; w < W; ++w) accP[w] |= xs[w + 1] ^ bp;
+                for (int w = 0; w < W; ++w) { accP[w] |= xs[w + 1] ^ bp; VF_KEEP(accP[w]); }
             }
             if (s0) {
                 const uint32_t bp = to_vgpr_u((uint32_t)((sp.suf_pat >> (2 * b)) & 3ull) * 0x55555555u);
 #pragma unroll
-                for (int w = 0; w < W; ++w) accS[w] |= xs[w] ^ bp;
+                for (int w = 0; w < W; ++w) { accS[w] |= xs[w] ^ bp; VF_KEEP(accS[w]); }
             }
             if (s1) {
                 const uint32_t bp = to_vgpr_u((uint32_t)((sp.suf_pat >> (2 * b + 32)) & 3ull) * 0x55555555u);
 #pragma unroll
-                for (int w = 0; w < W; ++w) accS[w] |= xs[w + 1] ^ bp;
+                for (int w = 0; w < W; ++w) { accS[w] |= xs[w + 1] ^ bp; VF_KEEP(accS[w]); }
             }
         }
     }
@@ -134,7 +140,7 @@ __device__ __forceinline__ void exact_find2(const uint32_t (&r)[W + 2], const ui
 #else
 #define VF_SCAN_ATTR __launch_bounds__(kBlock, VF_SCAN_WAVES)      // A/B: register cap (8 -> 64 registers: two waves fit a SIMD beside three k_finish waves)
 #endif
-template <int W>
+template <int W, bool P44>
 __global__ VF_SCAN_ATTR void k_scan(const uint32_t *__restrict__ rows, const uint16_t *__restrict__ lens,
                                                  uint64_t n_reads, ScanParams sp, short2 *__restrict__ spans,
                                                  BatchLists bl) {
@@ -172,7 +178,7 @@ __global__ VF_SCAN_ATTR void k_scan(const uint32_t *__restrict__ rows, const uin
         __builtin_amdgcn_wave_barrier();              // (nobody is still comparing against the previous trip's rows: lanes only read their own column, but keep the order explicit)
 #pragma unroll
         for (int w = 0; w < W; ++w) stg[w * WAVE + lane_id()] = x[w];
-        exact_find2<W>(x, stg + lane_id(), n, sp, ps, ss);
+        exact_find2<W, P44>(x, stg + lane_id(), n, sp, ps, ss);
         int start = ps >= 0 ? ps + (int)sp.pre_len : (sp.align_pre ? (int)kPending : (int)kNone);
         int end = ss >= 0 ? ss : ((sp.align_suf && (sp.independent || start != kNone)) ? (int)kPending : (int)kNone);
         const bool needP = valid && start == kPending;
@@ -842,7 +848,7 @@ __global__ VF_BMF_ATTR void k_bmfilter(DpParams dp,
 // ------------------------------------------------------------------------------------------------
 template <int W> static int scan_occupancy() {
     // the list segments k_scan writes are read by one workgroup each of the filter kernels: the same count has to suit them
-    int o = occupancy_of(k_scan<W>, 0);
+    int o = std::min(occupancy_of(k_scan<W, false>, 0), occupancy_of(k_scan<W, true>, 0));
     o = std::min(o, occupancy_of(k_filter<W>, 0));
     o = std::min(o, std::min(occupancy_of(k_bmfilter<W, 2>, 0), std::min(occupancy_of(k_bmfilter<W, 3>, 0), occupancy_of(k_bmfilter<W, 4>, 0))));
     return o;
@@ -877,10 +883,17 @@ hipError_t launch_scan(hipStream_t s, int W, const uint32_t *rows, const uint16_
     uint32_t g, seg;
     scan_geometry(n, W, &g, &seg);
     if (bl.grid != g || bl.seg != seg) return hipErrorInvalidValue;
+    const bool p44 = sp.pre_len >= 20 && sp.suf_len >= 20;        // scan_plan(m) = {4, 4} for every m >= 20
     switch (W) {
-    case 10: hipLaunchKernelGGL(k_scan<10>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, sp, spans, bl); break;
-    case 20: hipLaunchKernelGGL(k_scan<20>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, sp, spans, bl); break;
-    case 40: hipLaunchKernelGGL(k_scan<40>, dim3(g), dim3(kBlock), 0, s, rows, lens, n, sp, spans, bl); break;
+    case 10: if (p44) hipLaunchKernelGGL((k_scan<10, true>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, sp, spans, bl);
+             else hipLaunchKernelGGL((k_scan<10, false>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, sp, spans, bl);
+             break;
+    case 20: if (p44) hipLaunchKernelGGL((k_scan<20, true>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, sp, spans, bl);
+             else hipLaunchKernelGGL((k_scan<20, false>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, sp, spans, bl);
+             break;
+    case 40: if (p44) hipLaunchKernelGGL((k_scan<40, true>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, sp, spans, bl);
+             else hipLaunchKernelGGL((k_scan<40, false>), dim3(g), dim3(kBlock), 0, s, rows, lens, n, sp, spans, bl);
+             break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
