@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 
 
-def run(iters, seed, n_reads=1500, verbose=True):
+def run(iters, seed, n_reads=1500, verbose=True, long_reads=False):
     """-> list of (iteration, description) of every configuration whose device results differ from the oracle's"""
     import vfind_amd
     from oracle import oracle
@@ -22,7 +22,7 @@ def run(iters, seed, n_reads=1500, verbose=True):
                   gap_open_penalty=int(rng.integers(0, 9)), gap_extend_penalty=int(rng.integers(0, 5)),
                   accept_prefix_alignment=float(rng.choice([0.5, 0.6, 0.75, 0.9, 1.0, 0.83])),
                   accept_suffix_alignment=float(rng.choice([0.5, 0.6, 0.75, 0.9, 1.0, 0.67])))
-        L = int(rng.choice([40, 100, 150, 151, 250, 300]))
+        L = int(rng.choice([150, 300, 321, 420, 500, 639, 640] if long_reads else [40, 100, 150, 151, 250, 300]))     # (long: the 20- and 40-word rows)
         if L < mp + ms + 12:
             L = mp + ms + 40
         reads = synth.make_reads(int(rng.integers(1, 1 << 30)), n_reads, ads, L=L, sub=float(rng.choice([0.0, 0.02, 0.1])),
@@ -57,6 +57,7 @@ if __name__ == "__main__":
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     t0 = time.time()
-    bad = run(iters, seed)
-    print(f"{iters} iterations, {len(bad)} mismatches, {time.time() - t0:.1f}s", flush=True)
+    long_reads = len(sys.argv) > 3 and sys.argv[3] == "long"          # reads of 150-640 bp: the 20- and 40-word kernels
+    bad = run(iters, seed, n_reads=600 if long_reads else 1500, long_reads=long_reads)
+    print(f"{iters} iterations{' (long reads)' if long_reads else ''}, {len(bad)} mismatches, {time.time() - t0:.1f}s", flush=True)
     sys.exit(1 if bad else 0)
