@@ -254,12 +254,13 @@ def one_case(rng):
     hi = c[1] - dl if c[1] < n else n
     if not (hi >= lo and hi - lo + 2 * k_lo + 1 <= KBAND):
         return None
+    kband = KBAND_N if hi - lo + 2 * k_lo + 1 <= KBAND_N else KBAND       # (the narrow class: round 4, also from the Myers stage)
     av = lo - m - k_lo
     letters = b"ACGT"
     qb = bytes(letters[x] for x in ad)
     rb = bytes(letters[x] for x in read)
     fs, fl, _, _ = pyref.sg_stats_py(qb, rb, match, mismatch, gopen, gext)
-    bs, bl = banded(ad, read, av, match, mismatch, gopen, gext)
+    bs, bl = banded(ad, read, av, match, mismatch, gopen, gext, kband)
     ok_full, ok_band = fs >= T, bs >= T
     good = ok_full == ok_band and (not ok_full or (fs == bs and fl == bl))
     if not good:
@@ -512,6 +513,8 @@ def hamming_decision(ad, read, T, kerr, match, mismatch, gopen, gext, k_lo=None,
     if hi < lo:
         return None
     width = hi - lo + 2 * kq_used + 1
+    if width <= KBAND_N:
+        return KBAND_N, lo - m - kq_used, hmin, kq
     if width <= KBAND:
         return KBAND, lo - m - kq_used, hmin, kq
     if width <= KBAND_W:

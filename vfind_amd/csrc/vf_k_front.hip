@@ -573,11 +573,12 @@ __device__ __forceinline__ void hamming_band_class(const uint32_t *__restrict__ 
     const int hi = cl.jmax1 < n ? cl.jmax1 - dl : n;
     if (hi < lo) return;
     const int width = hi - lo + 2 * kq + 1;
-    if (width <= kBand) { cls = 0; av = lo - m - kq; }
+    if (width <= kBandN) { cls = 5; av = lo - m - kq; }         // (a single substitution: three diagonals)
+    else if (width <= kBand) { cls = 0; av = lo - m - kq; }
     else if (width <= kBandW) { cls = 6; av = lo - m - kq; }
 }
 
-// What the Myers pass makes of one task's clusters: cls 0 banded (kBand), 1..3 windowed, 4 whole read, 6 wide band (kBandW);
+// What the Myers pass makes of one task's clusters: cls 0 banded (kBand), 1..3 windowed, 4 whole read, 5 narrow band (kBandN), 6 wide band (kBandW);
 // av = first diagonal of a banded class, a1 / a2 = window starts.  (One place for k_filter and k_bmfilter's Myers stage.)
 template <int W>
 __device__ __forceinline__ void myers_classify(const uint32_t *__restrict__ row, int n, bool any, const Clusters &cl, const DpParams &dp,
@@ -596,10 +597,10 @@ __device__ __forceinline__ void myers_classify(const uint32_t *__restrict__ row,
         const int dl = dp.dl_lo;
         const int lo = cl.jmin1 > 1 ? cl.jmin1 + dl : 1;
         const int hi = cl.jmax1 < n ? cl.jmax1 - dl : n;
-        if (hi >= lo && hi - lo + 2 * dp.kerr_lo + 1 <= kBand) { cls = 0; av = lo - (int)dp.m - dp.kerr_lo; }
+        if (hi >= lo && hi - lo + 2 * dp.kerr_lo + 1 <= kBand) { cls = hi - lo + 2 * dp.kerr_lo + 1 <= kBandN ? 5 : 0; av = lo - (int)dp.m - dp.kerr_lo; }
     }
-    if (VF_HAMMING_CERT) hamming_band_class<W>(row, n, cl, dp, any && cls != 0 && cl.ncl == 1 && dp.kerr_h[0] != 0, cls, av);
-    if (cls != 0 && cls != 6 && wide_band_class(cl, dp, av)) cls = 6;
+    if (VF_HAMMING_CERT) hamming_band_class<W>(row, n, cl, dp, any && cls != 0 && cls != 5 && cl.ncl == 1 && dp.kerr_h[0] != 0, cls, av);
+    if (cls != 0 && cls != 5 && cls != 6 && wide_band_class(cl, dp, av)) cls = 6;
 }
 
 // the Myers pass alone, over every task of the adapter's list (scoring schemes that give the block filter no bound, or
@@ -608,7 +609,7 @@ template <int W>
 __global__ __launch_bounds__(kBlock) void k_filter(DpParams dp, short2 *__restrict__ spans, BatchLists bl,
                                                    uint64_t *__restrict__ counters) {
     const TaskSrc src{bl.rows, bl.lens, W};
-    __shared__ uint32_t s_c[6];
+    __shared__ uint32_t s_c[7];
     __shared__ uint2 s_eq2[16];
     if (threadIdx.x < 16) s_eq2[threadIdx.x] = make_uint2(dp.eq_top[threadIdx.x & 3], dp.eq_top[threadIdx.x >> 2]);
     const uint32_t *list = dp.is_prefix ? bl.listP : bl.listS;
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(kBlock) void k_filter(DpParams dp, short2 *__restri
     uint32_t stat = 0;
     for (uint32_t b = blockIdx.x; b < bl.grid; b += gridDim.x) {
         const uint32_t ntask = cnt[b];
-        if (threadIdx.x < 6) s_c[threadIdx.x] = 0u;
+        if (threadIdx.x < 7) s_c[threadIdx.x] = 0u;
         __syncthreads();
         const uint32_t n_round = (ntask + WAVE - 1) / WAVE * WAVE;
         const uint64_t seg0 = (uint64_t)b * bl.seg;
@@ -637,6 +638,9 @@ __global__ __launch_bounds__(kBlock) void k_filter(DpParams dp, short2 *__restri
                 const bool toB = any && cls == 6;
                 const uint32_t ib = wave_append(&s_c[5], toB);
                 if (toB) { bl.listB[seg0 + ib] = r; bl.winB[seg0 + ib] = (uint32_t)(av + kBandBias); }
+                const bool toN = any && cls == 5;
+                const uint32_t in = wave_append(&s_c[6], toN);
+                if (toN) { bl.listN[seg0 + in] = r; bl.winN[seg0 + in] = (uint32_t)(av + kBandBias); }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -657,7 +661,7 @@ __global__ __launch_bounds__(kBlock) void k_filter(DpParams dp, short2 *__restri
         if (threadIdx.x == 4) bl.cntF[b] = s_c[4];
         if (threadIdx.x == 6) { bl.cntB[b] = s_c[5]; if (s_c[5]) atomicAdd(&bl.tot[(dp.is_prefix ? 0u : 8u) + 6u], s_c[5]); }
         if (threadIdx.x < 5 && s_c[threadIdx.x]) atomicAdd(&bl.tot[(dp.is_prefix ? 0u : 8u) + threadIdx.x], s_c[threadIdx.x]);
-        if (threadIdx.x == 5) bl.cntN[b] = 0;
+        if (threadIdx.x == 5) { bl.cntN[b] = s_c[6]; if (s_c[6]) atomicAdd(&bl.tot[(dp.is_prefix ? 0u : 8u) + 5u], s_c[6]); }
         stat += ntask;
         __syncthreads();
     }
@@ -748,7 +752,7 @@ __device__ __forceinline__ void front_bf_stage(const TaskSrc &src, const DpParam
 template <int W>
 __device__ __forceinline__ void front_myers_stage(const TaskSrc &src, const DpParams &dp,
                                                   short2 *__restrict__ spans, const ClassSet &cs, uint32_t nR, uint64_t seg0,
-                                                  uint32_t *s_my, const uint2 *s_eq2) {
+                                                  uint32_t *s_my, const uint2 *s_eq2, uint32_t *s_narrow) {
     TripIter it(nR);
     const uint32_t ntrip = it.trips();
     uint32_t t = it.t;
@@ -772,6 +776,9 @@ __device__ __forceinline__ void front_myers_stage(const TaskSrc &src, const DpPa
             const bool toB = any && cls == 6;
             const uint32_t ib = wave_append(&s_my[5], toB);
             if (toB) { cs.listB[seg0 + ib] = r; cs.winB[seg0 + ib] = (uint32_t)(av + kBandBias); }
+            const bool toN = any && cls == 5;                   // behind the narrow tasks the block filter put into the segment
+            const uint32_t in = wave_append(s_narrow, toN);
+            if (toN) { cs.listN[seg0 + in] = r; cs.winN[seg0 + in] = (uint32_t)(av + kBandBias); }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -825,7 +832,7 @@ __global__ VF_BMF_ATTR void k_bmfilter(DpParams dp,
         const uint32_t nR = s_bf[2];
         if (threadIdx.x == 0) s_my[0] = s_bf[1];
         __syncthreads();
-        if (nR) front_myers_stage<W>(src, dp, spans, cs, nR, seg0, s_my, s_eq2);
+        if (nR) front_myers_stage<W>(src, dp, spans, cs, nR, seg0, s_my, s_eq2, &s_bf[0]);
         __syncthreads();
         if (threadIdx.x == 0) {
             bl.cntN[sb] = s_bf[0]; bl.cntR[sb] = nR;
