@@ -611,4 +611,10 @@ hipError_t launch_dp_classes(hipStream_t s, int W, const DpParams &dp, short2 *s
 }
 
 
+#ifdef VF_FINISH_ABLATION
+extern "C" int vf_debug_dp_trace(uint64_t *out) {          // diagnosis build: 2 x kMaxGrid x 4 words (scripts/dp_trace.py)
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dp_trace), sizeof(uint64_t) * 2 * kMaxGrid * 4) == hipSuccess ? 0 : 4;
+}
+#endif
+
 }  // namespace vf

@@ -1245,9 +1245,6 @@ __global__ __launch_bounds__(kBlock) void k_clear(ClearRegions cr) {
 extern "C" int vf_debug_fin_trace(uint64_t *out) {         // diagnosis build: kMaxGrid x 4 waves x 12 words
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_trace), sizeof(uint64_t) * kMaxGrid * (kBlock / WAVE) * 12) == hipSuccess ? 0 : 4;
 }
-extern "C" int vf_debug_dp_trace(uint64_t *out) {          // diagnosis build: 2 x kMaxGrid x 4 words
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dp_trace), sizeof(uint64_t) * 2 * kMaxGrid * 4) == hipSuccess ? 0 : 4;
-}
 #endif
 
 // A few words of device memory written straight into page-locked host memory by a one-wave kernel.  An 8-byte
