@@ -1392,6 +1392,38 @@ def test_merge_refuses_byte_keys_a_tagged_table_cannot_hold():
             dst.merge_from(blob.data_ptr(), n)
 
 
+def test_unit_distance_scan_keeps_its_coverage():
+    """VFIND_INDEL_SCAN=0: the unit-distance (Myers) scan for every scoring scheme - what every scheme got before round 4 and what
+    schemes with cheap substitutions still get.  The default scheme now takes the indel scan, so the suite would otherwise reach
+    the Myers path only through the fuzz's random schemes: here the shapes that stress it (15 % substitutions, indels, every read
+    length mod 16) run through it with the defaults - spans and table against the oracle.  (Read once per process: a child.)"""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+import vfind_amd
+from oracle import oracle
+from tests import synth
+AD20 = ("GATCGGAAGAGCACACGTCT", "AGATCGGAAGAGCGTCGTGT")
+tot = 0
+for seed, L, sub, indel in ((501, 150, 0.15, 0.0), (502, 151, 0.05, 0.03), (503, 157, 0.15, 0.0), (504, 160, 0.02, 0.01), (505, 300, 0.1, 0.01)):
+    rd = synth.make_reads(seed, 6000, AD20, L=L, sub=sub, indel=indel, flank_max=9, vary_len=True)
+    with vfind_amd.Engine(AD20, table_slots=1 << 15) as e:
+        st, en = e.spans(rd)
+        e.submit(rd)
+        got = e.finish_dict()
+        dup = e.stats()["dup_rows"]
+    ost, oen = oracle.spans(rd, AD20)
+    assert (st == ost).all() and (en == oen).all(), (seed, L)
+    assert got == oracle.count(rd, AD20) and dup == 0, (seed, L)
+    tot += len(got)
+print("unit scan ok", tot)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, VFIND_INDEL_SCAN="0"))
+    assert out.returncode == 0 and "unit scan ok" in out.stdout, out.stderr[-3000:]
+
+
 def test_resident_batch_cut_into_pieces():
     """VFIND_RES_SPLIT: a resident batch (vf_process_device_packed) cut into pieces that go down the batch lanes one after the
     other (also what a batch of more than 2^30 reads gets: task entries are 31-bit) - spans of every piece land at their reads'
